@@ -1,0 +1,193 @@
+/*
+ * instantrestore_hip.h - C ABI of the MI355X (gfx950) hot path of InstantRestore.
+ *
+ * This is the drop-in boundary of the build: a plain-C interface (raw device pointers,
+ * explicit strides, a hipStream_t passed as void*) that the Python host side binds with
+ * ctypes (instantrestore_amd/_lib.py) and that a maintainer of the reference would bind from
+ * face_replace/models/attn_processors.py.  The reference itself is pure
+ * PyTorch and has no FFI; each entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative ir_status on failure; nothing is
+ *     thrown across the ABI; ir_last_error_string() describes the last failure of the
+ *     calling thread;
+ *   - all device work is enqueued asynchronously on `stream` (a hipStream_t; NULL = the
+ *     legacy default stream); nothing synchronises, nothing allocates;
+ *   - the caller owns every buffer; the library keeps no state between calls;
+ *   - tensors are described by a base pointer plus strides IN ELEMENTS; the innermost
+ *     (head_dim) axis is always contiguous and head_dim is always IR_HEAD_DIM = 64
+ *     (SD-Turbo: attention_head_dim [5,10,20,20] x 64 channels);
+ *   - element type of q/k/v/out is selected by ir_dtype (fp16 or bf16, 2 bytes); softmax
+ *     statistics, AdaIN statistics and all accumulation are fp32.
+ */
+#ifndef INSTANTRESTORE_HIP_H
+#define INSTANTRESTORE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IR_ABI_VERSION 1
+#define IR_HEAD_DIM 64
+
+typedef enum ir_status {
+  IR_OK = 0,
+  IR_ERR_INVALID_ARG = -1, /* NULL pointer, negative size, bad stride, bad struct_size */
+  IR_ERR_UNSUPPORTED = -2, /* dtype / head_dim / alignment the kernels do not implement */
+  IR_ERR_LAUNCH = -3,      /* hipLaunchKernel reported an error (see ir_last_error_string) */
+  IR_ERR_WORKSPACE = -4    /* workspace too small */
+} ir_status;
+
+typedef enum ir_dtype { IR_DTYPE_F16 = 0, IR_DTYPE_BF16 = 1 } ir_dtype;
+
+/* flags of ir_shared_attn_args.flags */
+#define IR_FLAG_INCLUDE_SELF 1u /* train_input: self K/V block precedes the reference blocks */
+
+/*
+ * ir_shared_attn_fwd - fused extended self-attention (flash-style, no probability matrix).
+ *
+ * Replaces the body of SharedAttnProcessor.forward between the q/k/v projections and to_out
+ * (face_replace/models/attn_processors.py:232-264): the 3+2N head_to_batch_dim copies
+ * (:232-241), adain() of every reference V (:242-246, when adain_a/adain_b are given), the
+ * torch.cat of the extended K/V (:247-252), get_attention_scores = baddbmm+softmax (:257,
+ * diffusers 0.24 Attention) and the bmm + batch_to_head_dim (:263-264).  With n_refs == 0 it is
+ * the plain attention of AttnProcessor.forward (:76-82) and of the self_attn_idx=None branch
+ * (:253-255), cross attention included (kv length = len_self).
+ *
+ *   O[b,i,h,:] = sum_j softmax_j( scale * <Q[b,i,h,:], K_ext[b,j,h,:]> ) * V_ext[b,j,h,:]
+ *   K_ext / V_ext column order: [self tokens (iff IR_FLAG_INCLUDE_SELF)] ++ ref 0 ++ ... ++ ref N-1
+ *   V_ext of reference n is  v_ref[b,n,j,h,d] * adain_a[b,n,h,d] + adain_b[b,n,h,d]  (if given).
+ *
+ * Layouts (strides in elements, d contiguous):
+ *   q      (B, len_q,   H, 64)  strides q_sb, q_sl, q_sh
+ *   k_self (B, len_self,H, 64)  strides ks_sb, ks_sl, ks_sh      v_self: vs_*
+ *   k_ref  (B, N, len_ref, H, 64) strides kr_sb, kr_sn, kr_sl, kr_sh   v_ref: vr_*
+ *   out    (B, len_q,   H, 64)  strides o_sb, o_sl, o_sh
+ *   adain_a, adain_b : fp32 (B, N, H, 64) contiguous, or both NULL
+ *   lse    : fp32 (B, H, len_q) contiguous or NULL; natural-log sum-exp of the scaled scores
+ * i.e. a (B, L, C=H*64) activation is passed as is with sl = C, sh = 64, and the reference's
+ * ref_keys[idx] (B, N, L, C) with sn = L*C (pix2pix_turbo.py:265-266): nothing is copied.
+ * All base pointers and strides must keep every (row, head) vector 16-byte aligned.
+ */
+typedef struct ir_shared_attn_args {
+  uint32_t struct_size; /* = sizeof(ir_shared_attn_args) */
+  int32_t dtype;        /* ir_dtype */
+  uint32_t flags;       /* IR_FLAG_* */
+  int32_t batch;        /* B */
+  int32_t heads;        /* H */
+  int32_t len_q;        /* query tokens */
+  int32_t len_self;     /* tokens of k_self / v_self (0 allowed iff !INCLUDE_SELF) */
+  int32_t n_refs;       /* N (0 = plain attention) */
+  int32_t len_ref;      /* tokens per reference */
+  float scale;          /* attn.scale = head_dim ** -0.5 */
+  const void* q;
+  const void* k_self;
+  const void* v_self;
+  const void* k_ref;
+  const void* v_ref;
+  const float* adain_a;
+  const float* adain_b;
+  void* out;
+  float* lse;
+  int64_t q_sb, q_sl, q_sh;
+  int64_t ks_sb, ks_sl, ks_sh;
+  int64_t vs_sb, vs_sl, vs_sh;
+  int64_t kr_sb, kr_sn, kr_sl, kr_sh;
+  int64_t vr_sb, vr_sn, vr_sl, vr_sh;
+  int64_t o_sb, o_sl, o_sh;
+} ir_shared_attn_args;
+
+int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream);
+
+/*
+ * ir_attn_probs - materialise attention_probs (B, H, len_q, Lkv) for the dump path.
+ *
+ * Replaces `self.attention_probs = attention_probs.reshape(B, heads, L, Lkv)`
+ * (attn_processors.py:258-261), read by test.py:108, gradio_demo.py:118, coach.py:312.
+ * Uses the same args as ir_shared_attn_fwd (out / adain_* are ignored) plus the `lse` that
+ * call produced:  probs[b,h,i,j] = exp(scale*<q_i,k_j> - lse[b,h,i]), stored in `dtype`,
+ * contiguous, column order as above.
+ */
+int ir_attn_probs(const ir_shared_attn_args* args, void* probs, void* stream);
+
+/*
+ * ir_adain_stats - per-(b, n, channel) AdaIN affine from token statistics.
+ *
+ * Replaces the statistics half of adain() (attn_processors.py:9-10) and of its call site
+ * (:244-245): mean and UNBIASED standard deviation over the token axis of the degraded
+ * image's V (style) and of every reference V (content), eps = 1e-5 added to both deviations:
+ *      a = (std(v_self)+eps) / (std(v_ref_n)+eps),   b = mean(v_self) - mean(v_ref_n) * a
+ * so that adain(v_ref_n) == v_ref_n * a + b.  One pass over the data, fp32 Chan/Welford merge.
+ *   v_self (B, len_self, H, 64) strides vs_*;  v_ref (B, N, len_ref, H, 64) strides vr_*
+ *   a, b : fp32 (B, N, H, 64) contiguous
+ *   workspace: >= ir_adain_stats_workspace_bytes(...) bytes of device memory
+ */
+size_t ir_adain_stats_workspace_bytes(int32_t batch, int32_t heads, int32_t len_self, int32_t n_refs,
+                                      int32_t len_ref);
+int ir_adain_stats(int32_t dtype, int32_t batch, int32_t heads, int32_t len_self, int32_t n_refs,
+                   int32_t len_ref, const void* v_self, int64_t vs_sb, int64_t vs_sl, int64_t vs_sh,
+                   const void* v_ref, int64_t vr_sb, int64_t vr_sn, int64_t vr_sl, int64_t vr_sh,
+                   float eps, float* a, float* b, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * ir_token_stats - mean and UNBIASED standard deviation over the token axis.
+ *
+ * The content-statistics lines of adain() on their own (attn_processors.py:9-10, without the
+ * +1e-5): used by the exported adain(content, style_mean, style_std), whose style statistics
+ * arrive precomputed.   x (B, M, len, H, 64) strides x_*;  mean, std: fp32 (B, M, H, 64).
+ * workspace >= ir_adain_stats_workspace_bytes(batch, heads, len, n_mats - 1, len).
+ */
+int ir_token_stats(int32_t dtype, int32_t batch, int32_t heads, int32_t n_mats, int32_t len,
+                   const void* x, int64_t x_sb, int64_t x_sn, int64_t x_sl, int64_t x_sh,
+                   float* mean, float* std, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * ir_adain_apply - standalone AdaIN application  y = x * a + b  (fp32 math, stored in dtype).
+ *
+ * Replaces the normalise/scale/shift half of adain() (attn_processors.py:12-16) for callers
+ * that need the renormalised V materialised (op-level parity, the exported adain()).  The fused
+ * attention folds the same affine into its V staging and never writes this tensor.
+ *   x, y (B, N, len, H, 64) with strides x_* / y_*;  a, b fp32 (B, N, H, 64) contiguous
+ */
+int ir_adain_apply(int32_t dtype, int32_t batch, int32_t heads, int32_t n_refs, int32_t len,
+                   const void* x, int64_t x_sb, int64_t x_sn, int64_t x_sl, int64_t x_sh,
+                   const float* a, const float* b,
+                   void* y, int64_t y_sb, int64_t y_sn, int64_t y_sl, int64_t y_sh, void* stream);
+
+/*
+ * ir_zero_invalid_refs - zero the K and V of references n >= valid[b] in place.
+ *
+ * Replaces the Python double loop of Pix2Pix_Turbo.get_conditioning_keys_values
+ * (face_replace/models/pix2pix_turbo.py:269-273).  Zeroed, not masked: the tokens keep their
+ * exp(0) softmax weight, exactly like the reference.  valid: int32 (B) on the device.
+ *   k, v (B, N, len, H*64) described as (B, N, len, H, 64) with strides *_sb,_sn,_sl,_sh
+ */
+int ir_zero_invalid_refs(int32_t batch, int32_t heads, int32_t n_refs, int32_t len, const int32_t* valid,
+                         void* k, int64_t k_sb, int64_t k_sn, int64_t k_sl, int64_t k_sh,
+                         void* v, int64_t v_sb, int64_t v_sn, int64_t v_sl, int64_t v_sh, void* stream);
+
+/* library identity / diagnostics */
+int ir_abi_version(void);                  /* == IR_ABI_VERSION */
+const char* ir_build_info(void);           /* "gfx950 hipcc ... <date>" */
+const char* ir_last_error_string(void);    /* thread-local, never NULL */
+
+/*
+ * Tuning hook (benchmarks / tests only): selects a kernel variant for subsequent
+ * ir_shared_attn_fwd calls of this process. 0 = default. Returns the previous value.
+ */
+int ir_set_attn_variant(int variant);
+
+/*
+ * ir_time_shared_attn_fwd - launch ir_shared_attn_fwd `iters` times on `stream` bracketed by
+ * HIP events recorded on that same stream and return the average milliseconds per launch in
+ * *ms_per_launch (bench.py's live roofline measurement; synchronises the stream).
+ */
+int ir_time_shared_attn_fwd(const ir_shared_attn_args* args, int32_t iters, void* stream, float* ms_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INSTANTRESTORE_HIP_H */

@@ -1,0 +1,279 @@
+"""Attention processors of InstantRestore, MI355X-native.
+
+Drop-in for ``face_replace/models/attn_processors.py`` of the reference: the same six public
+names, constructor signatures, ``forward`` signatures, attribute protocol
+(``self_attn_idx``, ``save_self_attentions``, ``attention_probs``, ``keys``/``values``/
+``reset()``) and registration functions.  The projections (``to_q/k/v``,
+``to_out``) stay ``nn.Linear`` calls on the host ``attn`` object exactly as in the reference -
+so peft/LoRA wrappers and autocast keep working - while everything between them, which the
+reference spells as head-split copies + ``adain`` + ``cat`` + ``baddbmm``/``softmax``/``bmm``
+(attn_processors.py:232-264), is ONE fused HIP kernel plus a one-pass statistics kernel
+(``instantrestore_amd.ops`` -> ``include/instantrestore_hip.h``).
+
+The processors own no parameters and no buffers (the reference's checkpoints are loaded with
+``strict=True``, test.py:47-50).  They never fall back to torch math: CPU tensors, fp32
+activations outside autocast, attention masks and missing libraries raise.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import ops as _ops  # tests swap this module-level name for an oracle-backed stand-in
+
+
+# ------------------------------------------------------------------------------------------
+# adain(): attn_processors.py:7-18
+# ------------------------------------------------------------------------------------------
+def adain(content_features: torch.Tensor, style_mean: torch.Tensor, style_std: torch.Tensor) -> torch.Tensor:
+    """Renormalise ``content_features`` (BH, L, 64) to the given style statistics.
+
+    Same contract as the reference function: statistics over the token axis (dim=1), unbiased
+    std, ``1e-5`` added to the content std here (the caller has already added it to
+    ``style_std``, attn_processors.py:245).  The reduction and the application are HIP kernels;
+    only the (BH, 1, 64)-sized algebra that turns four statistics into an affine is torch.
+    """
+    if content_features.dim() != 3 or content_features.shape[-1] != _ops.HEAD_DIM:
+        raise ValueError("adain expects head-split features of shape (B*H, L, 64)")
+    bh, length, d = content_features.shape
+    x = content_features.reshape(bh, 1, length, d)
+    mean, std = _ops.token_stats(x, heads=1)                      # (BH,1,1,64) fp32
+    a = style_std.reshape(bh, 1, 1, d).float() / (std + _ops.ADAIN_EPS)
+    b = style_mean.reshape(bh, 1, 1, d).float() - mean * a
+    return _ops.adain_apply(x, a.contiguous(), b.contiguous(), heads=1).reshape(bh, length, d)
+
+
+# ------------------------------------------------------------------------------------------
+# shared prologue / epilogue of every processor (attn_processors.py:42-70, 84-97)
+# ------------------------------------------------------------------------------------------
+class _Prepared:
+    __slots__ = ("hidden", "encoder", "residual", "ndim", "shape4")
+
+
+def _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb) -> _Prepared:
+    st = _Prepared()
+    st.residual = hidden_states
+    if attn.spatial_norm is not None:
+        hidden_states = attn.spatial_norm(hidden_states, temb)
+    st.ndim = hidden_states.ndim
+    st.shape4 = None
+    if st.ndim == 4:
+        st.shape4 = hidden_states.shape
+        bsz, ch, hh, ww = st.shape4
+        hidden_states = hidden_states.view(bsz, ch, hh * ww).transpose(1, 2)
+    ref = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+    if attn.prepare_attention_mask(attention_mask, ref.shape[1], ref.shape[0]) is not None:
+        raise NotImplementedError("attention masks do not occur on the InstantRestore path")
+    if attn.group_norm is not None:
+        hidden_states = attn.group_norm(hidden_states.transpose(1, 2)).transpose(1, 2)
+    st.hidden = hidden_states
+    st.encoder = encoder_hidden_states
+    return st
+
+
+def _kv_source(attn, st: _Prepared) -> torch.Tensor:
+    if st.encoder is None:
+        return st.hidden
+    if attn.norm_cross:
+        return attn.norm_encoder_hidden_states(st.encoder)
+    return st.encoder
+
+
+def _epilogue(attn, st: _Prepared, tokens: torch.Tensor) -> torch.Tensor:
+    out = attn.to_out[0](tokens)   # linear proj (LoRA-wrapped on the main UNet)
+    out = attn.to_out[1](out)      # dropout (p = 0)
+    if st.ndim == 4:
+        bsz, ch, hh, ww = st.shape4
+        out = out.transpose(-1, -2).reshape(bsz, ch, hh, ww)
+    if attn.residual_connection:
+        out = out + st.residual
+    return out / attn.rescale_output_factor
+
+
+def _same_16bit(q: torch.Tensor, *others: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:
+    """Under autocast the projections emit fp16/bf16; captured reference K/V have that dtype
+    too.  Anything else on this path is a caller error worth hearing about."""
+    res = []
+    for t in others:
+        if t is not None and t.dtype != q.dtype:
+            raise TypeError(f"shared attention: query is {q.dtype} but a key/value tensor is {t.dtype}")
+        res.append(t)
+    return res
+
+
+# ------------------------------------------------------------------------------------------
+# K/V-capturing processor of the frozen reference UNet (attn_processors.py:22-97)
+# ------------------------------------------------------------------------------------------
+class AttnProcessor(nn.Module):
+    r"""Plain attention that stashes the PRE-head-split ``key`` / ``value`` projections
+    ``(B*N, L, C)`` for later sharing (attn_processors.py:73-74)."""
+
+    def __init__(self):
+        super().__init__()
+        self.keys, self.values = None, None
+        self.is_self_attn = None
+
+    def reset(self):
+        self.keys, self.values = None, None
+        self.is_self_attn = None
+
+    def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
+        st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+        query = attn.to_q(st.hidden)
+        self.is_self_attn = encoder_hidden_states is None
+        src = _kv_source(attn, st)
+        key, value = attn.to_k(src), attn.to_v(src)
+        self.keys, self.values = key, value  # consumed in place by the shared layers: no copies
+        _same_16bit(query, key, value)
+        tokens = _ops.shared_attention(query, key, value, heads=attn.heads, scale=attn.scale, include_self=True)
+        return _epilogue(attn, st, tokens)
+
+
+# ------------------------------------------------------------------------------------------
+# face-embedding cross attention (attn_processors.py:100-180); off by default in the configs
+# ------------------------------------------------------------------------------------------
+class FaceIDAttnProcessor(nn.Module):
+    def __init__(self, hidden_size, self_attn_idx=None, cross_attention_dim=None, embed_dim: int = 512):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.cross_attention_dim = cross_attention_dim
+        width = cross_attention_dim or hidden_size
+        self.face_projection = nn.Linear(embed_dim, width)
+        self.to_k_face_embed = nn.Linear(width, hidden_size, bias=False)
+        self.to_v_face_embed = nn.Linear(width, hidden_size, bias=False)
+        self.self_attn_idx = self_attn_idx
+        self.keys, self.values = None, None
+        self.is_self_attn = None
+
+    def reset(self):
+        self.keys, self.values = None, None
+        self.is_self_attn = None
+
+    def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                ref_keys=None, ref_values=None):  # ref_* accepted and ignored, like the reference
+        st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+        self.is_self_attn = encoder_hidden_states is None
+        query = attn.to_q(st.hidden)
+        src = self.face_projection(_kv_source(attn, st))
+        key, value = self.to_k_face_embed(src), self.to_v_face_embed(src)
+        _same_16bit(query, key, value)
+        tokens = _ops.shared_attention(query, key, value, heads=attn.heads, scale=attn.scale, include_self=True)
+        return _epilogue(attn, st, tokens)
+
+
+# ------------------------------------------------------------------------------------------
+# the hot path: shared-image attention (attn_processors.py:183-279)
+# ------------------------------------------------------------------------------------------
+class SharedAttnProcessor(nn.Module):
+    r"""Extended self-attention over ``[self K/V (iff train_input)] ++ N x reference K/V``.
+
+    ``ref_keys[self_attn_idx]`` / ``ref_values[...]`` are the ``(B, N, L, C)`` tensors produced
+    by ``get_conditioning_keys_values`` (pix2pix_turbo.py:265-266); they are read in place by the
+    kernel (segment walk) - N is taken from the tensor, zero-filled references keep their
+    ``exp(0)`` weight, and with ``use_adain`` every reference V is renormalised to the
+    statistics of this image's own V inside the kernel's V staging.
+    """
+
+    def __init__(self, self_attn_idx: int = None, save_self_attentions: bool = False,
+                 use_adain: bool = False, train_input: bool = True):
+        super().__init__()
+        self.self_attn_idx = self_attn_idx
+        self.save_self_attentions = save_self_attentions
+        self.use_adain = use_adain
+        self.train_input = train_input
+
+    def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
+                ref_keys=None, ref_values=None):
+        st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
+        query = attn.to_q(st.hidden)
+        src = _kv_source(attn, st)
+        key, value = attn.to_k(src), attn.to_v(src)
+
+        ref_k = ref_v = None
+        include_self = True
+        affine = None
+        if self.self_attn_idx is not None and ref_keys is not None and ref_values is not None:
+            ref_k = ref_keys[self.self_attn_idx]
+            ref_v = ref_values[self.self_attn_idx]
+            include_self = bool(self.train_input)
+            if self.use_adain:
+                # style = this image's own post-projection V; content = each reference V
+                affine = _ops.adain_stats(value, ref_v, heads=attn.heads)
+        _same_16bit(query, key, value, ref_k, ref_v)
+
+        want_probs = bool(self.save_self_attentions)
+        res = _ops.shared_attention(query, key, value, ref_k, ref_v, heads=attn.heads, scale=attn.scale,
+                                    include_self=include_self, adain=affine, return_lse=want_probs)
+        if want_probs:
+            tokens, lse = res
+            # (B, H, L, Lkv), columns [self?] ++ ref0 ++ ... ++ refN-1, in the compute dtype
+            self.attention_probs = _ops.attn_probs(query, key, ref_k, lse, heads=attn.heads, scale=attn.scale,
+                                                   include_self=include_self)
+        else:
+            tokens = res
+        return _epilogue(attn, st, tokens)
+
+
+# ------------------------------------------------------------------------------------------
+# registration: the plugin boundary (attn_processors.py:282-331)
+# ------------------------------------------------------------------------------------------
+def _hidden_size_for(name: str, block_out_channels) -> Optional[int]:
+    if name.startswith("mid_block"):
+        return block_out_channels[-1]
+    if name.startswith("up_blocks"):
+        return list(reversed(block_out_channels))[int(name[len("up_blocks.")])]
+    if name.startswith("down_blocks"):
+        return block_out_channels[int(name[len("down_blocks.")])]
+    return None
+
+
+def register_attention_processor(unet, cfg, save_self_attentions: bool = False):
+    """Install a :class:`SharedAttnProcessor` on every attention of the main UNet.
+
+    Walks ``unet.attn_processors`` in registration order; the ``up_blocks.*attn1`` layers get
+    ``self_attn_idx`` 0..8 (``up_blocks.1.attentions.{0,1,2}``, then ``.2``, then ``.3``); all
+    other self-attentions and every cross-attention get ``self_attn_idx=None`` (cross-attention
+    becomes :class:`FaceIDAttnProcessor` when ``cfg.condition_on_face_embeds``).  ``cfg`` is the
+    reference's ``ModelConfig`` or anything with ``use_adain``, ``train_input`` and
+    ``condition_on_face_embeds`` attributes.
+    """
+    procs = {}
+    next_idx = 0
+    face_ids = bool(getattr(cfg, "condition_on_face_embeds", False))
+    for name in unet.attn_processors.keys():
+        is_cross = not name.endswith("attn1.processor")
+        if is_cross:
+            if face_ids:
+                proc = FaceIDAttnProcessor(hidden_size=_hidden_size_for(name, unet.config.block_out_channels),
+                                           self_attn_idx=None,
+                                           cross_attention_dim=unet.config.cross_attention_dim, embed_dim=512)
+            else:
+                proc = SharedAttnProcessor(self_attn_idx=None, use_adain=cfg.use_adain, train_input=cfg.train_input)
+        elif name.startswith("up_blocks") and "attn1" in name:
+            proc = SharedAttnProcessor(self_attn_idx=next_idx, save_self_attentions=save_self_attentions,
+                                       use_adain=cfg.use_adain, train_input=cfg.train_input)
+            next_idx += 1
+        else:
+            proc = SharedAttnProcessor(self_attn_idx=None, save_self_attentions=save_self_attentions,
+                                       use_adain=cfg.use_adain, train_input=cfg.train_input)
+        procs[name] = proc.to(unet.device, dtype=unet.dtype)
+    unet.set_attn_processor(procs)
+
+
+def register_attention_processor_kv_unet(unet):
+    """Put the K/V-capturing :class:`AttnProcessor` on the decoder self-attentions of the frozen
+    reference UNet and leave every other processor as it is (attn_processors.py:324-331)."""
+    current = unet.attn_processors
+    procs = {}
+    for name, proc in current.items():
+        if name.startswith("up_blocks") and "attn1" in name:
+            procs[name] = AttnProcessor().to(unet.device, dtype=unet.dtype)
+        else:
+            procs[name] = proc
+    unet.set_attn_processor(procs)
+
+
+__all__ = ["adain", "AttnProcessor", "FaceIDAttnProcessor", "SharedAttnProcessor",
+           "register_attention_processor", "register_attention_processor_kv_unet"]

@@ -1,0 +1,237 @@
+// adain.hip - AdaIN statistics / application and the invalid-reference zero fill (gfx950).
+//
+// adain() of face_replace/models/attn_processors.py:7-18 renormalises every reference V to the
+// degraded image's V statistics (call site :242-246).  It is an HBM-streaming op: here the
+// statistics are ONE pass over V_self and the N reference V's (each element read exactly once,
+// 16-byte loads, 128-byte head rows), merged in fp32 with Chan's parallel-variance formula, and
+// the result is emitted as a per-(b, n, head, channel) affine  x*a + b  that the attention kernel
+// folds into its V staging - the renormalised V is never written to memory.
+#include "ir_common.h"
+#include "ir_kernels.h"
+
+namespace {
+
+constexpr int ROWS = IR_ADAIN_ROWS;  // token rows per workgroup
+constexpr int AT = 256;              // threads: 32 row slots x 8 sixteen-byte column slots
+
+// Chan et al. merge of (n, mean, M2) partials.
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
+  if (nb == 0.f) return;
+  const float nt = n + nb;
+  const float delta = meanb - mean;
+  const float f = nb / nt;
+  mean = mean + delta * f;
+  m2 = m2 + m2b + delta * delta * n * f;
+  n = nt;
+}
+
+// grid: (nchunk, H, B*(1+N)); one workgroup reduces ROWS tokens of one head of one matrix.
+template <typename T>
+__global__ void __launch_bounds__(AT) adain_partial_kernel(const AdainKParams p) {
+  using v8 = typename ElemTraits<T>::v8;
+  __shared__ float red[32][8][17];  // [row slot][col slot][n, mean[8], m2[8]]
+
+  const int mat = blockIdx.z;
+  const int h = blockIdx.y;
+  const int chunk = blockIdx.x;
+  const int b = mat / (1 + p.N);
+  const int j = mat - b * (1 + p.N);  // 0 = self V, 1.. = reference j-1
+  const T* base;
+  int64_t sl;
+  int len;
+  if (j == 0) {
+    base = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
+    sl = p.vs_sl; len = p.Ls;
+  } else {
+    base = (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)(j - 1) * p.vr_sn + (int64_t)h * p.vr_sh;
+    sl = p.vr_sl; len = p.Lr;
+  }
+  const int r_begin = chunk * ROWS;
+  const int r_end = (r_begin + ROWS < len) ? r_begin + ROWS : len;
+  float* wsp = p.ws + (((int64_t)mat * p.H + h) * p.nchunk + chunk) * 128;
+
+  const int tid = threadIdx.x;
+  const int slot = tid & 7;
+  const int rs = tid >> 3;
+
+  // shifted single-pass sums: K = first value seen by this thread (kills cancellation)
+  float cnt = 0.f, K[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { K[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+  constexpr int PER = ROWS / 32;
+  v8 xs[PER];
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    int r = r_begin + rs + it * 32;
+    const int rc = r < r_end ? r : (r_end - 1 > 0 ? r_end - 1 : 0);
+    xs[it] = *(const v8*)(base + (int64_t)rc * sl + slot * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    const int r = r_begin + rs + it * 32;
+    if (r < r_end) {
+      const f32x8 f = __builtin_convertvector(xs[it], f32x8);
+      if (cnt == 0.f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) K[i] = f[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = f[i] - K[i];
+        s1[i] += d;
+        s2[i] = __builtin_fmaf(d, d, s2[i]);
+      }
+      cnt += 1.f;
+    }
+  }
+  {
+    float* o = &red[rs][slot][0];
+    o[0] = cnt;
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      o[1 + i] = K[i] + s1[i] * inv;
+      o[9 + i] = s2[i] - s1[i] * s1[i] * inv;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {  // one thread per channel merges the 32 row-slot partials
+    const int cs = tid >> 3, ci = tid & 7;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < 32; ++k) {
+      const float* o = &red[k][cs][0];
+      chan_merge(n, mean, m2, o[0], o[1 + ci], o[9 + ci]);
+    }
+    wsp[tid] = mean;
+    wsp[64 + tid] = m2;
+  }
+}
+
+// grid: (B*N*H); 64 threads = channels. Merges chunk partials, emits the affine.
+__global__ void __launch_bounds__(64) adain_finalize_kernel(const AdainKParams p) {
+  const int d = threadIdx.x;
+  int idx = blockIdx.x;
+  const int h = idx % p.H; idx /= p.H;
+  const int n = idx % p.N;
+  const int b = idx / p.N;
+
+  auto total = [&](int mat, int len, float& mean, float& m2) {
+    float cn = 0.f; mean = 0.f; m2 = 0.f;
+    const int nch = (len + ROWS - 1) / ROWS;
+    const float* w = p.ws + (((int64_t)mat * p.H + h) * p.nchunk) * 128;
+    for (int c = 0; c < nch; ++c) {
+      const int rows = (c + 1) * ROWS <= len ? ROWS : len - c * ROWS;
+      chan_merge(cn, mean, m2, (float)rows, w[c * 128 + d], w[c * 128 + 64 + d]);
+    }
+  };
+  float mu_v, m2_v, mu_x, m2_x;
+  total(b * (1 + p.N), p.Ls, mu_v, m2_v);
+  total(b * (1 + p.N) + 1 + n, p.Lr, mu_x, m2_x);
+  // torch.std default: unbiased (n-1); a single token gives 0/0 = NaN exactly like torch
+  const float sd_v = sqrtf(m2_v / (float)(p.Ls - 1)) + p.eps;
+  const float sd_x = sqrtf(m2_x / (float)(p.Lr - 1)) + p.eps;
+  const float a = sd_v / sd_x;
+  const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
+  p.a[o] = a;
+  p.b[o] = mu_v - mu_x * a;
+}
+
+// grid: (B*(1+N)*H); 64 threads. Plain token statistics (mean, unbiased std) of every matrix.
+__global__ void __launch_bounds__(64) token_stats_finalize_kernel(const AdainKParams p) {
+  const int d = threadIdx.x;
+  int idx = blockIdx.x;
+  const int h = idx % p.H;
+  const int mat = idx / p.H;
+  const int j = mat % (1 + p.N);
+  const int len = (j == 0) ? p.Ls : p.Lr;
+  float cn = 0.f, mean = 0.f, m2 = 0.f;
+  const int nch = (len + ROWS - 1) / ROWS;
+  const float* w = p.ws + (((int64_t)mat * p.H + h) * p.nchunk) * 128;
+  for (int c = 0; c < nch; ++c) {
+    const int rows = (c + 1) * ROWS <= len ? ROWS : len - c * ROWS;
+    chan_merge(cn, mean, m2, (float)rows, w[c * 128 + d], w[c * 128 + 64 + d]);
+  }
+  const int64_t o = ((int64_t)mat * p.H + h) * 64 + d;
+  p.a[o] = mean;
+  p.b[o] = sqrtf(m2 / (float)(len - 1));
+}
+
+// y = x*a + b over (B,N,L,H,64); one thread = one 16-byte slot, grid-stride over head rows.
+template <typename T>
+__global__ void __launch_bounds__(256) adain_apply_kernel(const AdainApplyKParams p) {
+  using v8 = typename ElemTraits<T>::v8;
+  const int slot = threadIdx.x & 7;
+  const int64_t rows = (int64_t)p.B * p.N * p.L * p.H;
+  for (int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); row < rows; row += (int64_t)gridDim.x * 32) {
+    int64_t t = row;
+    const int h = (int)(t % p.H); t /= p.H;
+    const int l = (int)(t % p.L); t /= p.L;
+    const int n = (int)(t % p.N);
+    const int b = (int)(t / p.N);
+    const T* x = (const T*)p.x + (int64_t)b * p.x_sb + (int64_t)n * p.x_sn + (int64_t)l * p.x_sl + (int64_t)h * p.x_sh + slot * 8;
+    T* y = (T*)p.y + (int64_t)b * p.y_sb + (int64_t)n * p.y_sn + (int64_t)l * p.y_sl + (int64_t)h * p.y_sh + slot * 8;
+    const int64_t ao = (((int64_t)b * p.N + n) * p.H + h) * 64 + slot * 8;
+    f32x8 f = __builtin_convertvector(*(const v8*)x, f32x8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = __builtin_fmaf(f[i], p.a[ao + i], p.b[ao + i]);
+    *(v8*)y = __builtin_convertvector(f, v8);
+  }
+}
+
+// zero K and V of references n >= valid[b] (pix2pix_turbo.py:269-273); grid (row chunks, N, B)
+__global__ void __launch_bounds__(256) zero_refs_kernel(const ZeroRefsKParams p) {
+  const int b = blockIdx.z, n = blockIdx.y;
+  if (n < p.valid[b]) return;
+  const int slot = threadIdx.x & 7;
+  const int64_t rows = (int64_t)p.L * p.H;
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (int64_t row = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); row < rows; row += (int64_t)gridDim.x * 32) {
+    const int h = (int)(row % p.H);
+    const int64_t l = row / p.H;
+    unsigned short* k = (unsigned short*)p.k + (int64_t)b * p.k_sb + (int64_t)n * p.k_sn + l * p.k_sl + (int64_t)h * p.k_sh + slot * 8;
+    unsigned short* v = (unsigned short*)p.v + (int64_t)b * p.v_sb + (int64_t)n * p.v_sn + l * p.v_sl + (int64_t)h * p.v_sh + slot * 8;
+    *(uint4*)k = z;
+    *(uint4*)v = z;
+  }
+}
+
+}  // namespace
+
+hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s) {
+  const dim3 grid(p.nchunk, p.H, p.B * (1 + p.N));
+  if (dtype == 1) hipLaunchKernelGGL((adain_partial_kernel<__bf16>), grid, dim3(AT), 0, s, p);
+  else hipLaunchKernelGGL((adain_partial_kernel<_Float16>), grid, dim3(AT), 0, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(adain_finalize_kernel, dim3(p.B * p.N * p.H), dim3(64), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t ir_launch_token_stats(const AdainKParams& p, int dtype, hipStream_t s) {
+  const dim3 grid(p.nchunk, p.H, p.B * (1 + p.N));
+  if (dtype == 1) hipLaunchKernelGGL((adain_partial_kernel<__bf16>), grid, dim3(AT), 0, s, p);
+  else hipLaunchKernelGGL((adain_partial_kernel<_Float16>), grid, dim3(AT), 0, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(token_stats_finalize_kernel, dim3(p.B * (1 + p.N) * p.H), dim3(64), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t ir_launch_adain_apply(const AdainApplyKParams& p, int dtype, hipStream_t s) {
+  const int64_t rows = (int64_t)p.B * p.N * p.L * p.H;
+  int64_t blocks = (rows + 31) / 32;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  if (dtype == 1) hipLaunchKernelGGL((adain_apply_kernel<__bf16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((adain_apply_kernel<_Float16>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t ir_launch_zero_refs(const ZeroRefsKParams& p, hipStream_t s) {
+  const int64_t rows = (int64_t)p.L * p.H;
+  int64_t bx = (rows + 31) / 32;
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(zero_refs_kernel, dim3((unsigned)bx, p.N, p.B), dim3(256), 0, s, p);
+  return hipGetLastError();
+}

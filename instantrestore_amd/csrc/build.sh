@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+# Build libinstantrestore_hip.so (gfx950 only) in-tree, next to the Python package.
+# hipcc cross-compiles without a GPU. Usage: build.sh [extra hipcc flags]
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+OUT="${HERE}/../libinstantrestore_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+SRCS=(shared_attn_fwd.hip attn_probs.hip adain.hip c_abi.hip)
+cd "${HERE}"
+OBJS=()
+pids=()
+mkdir -p build
+for s in "${SRCS[@]}"; do
+  o="build/${s%.hip}.o"
+  OBJS+=("$o")
+  "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$s" -o "$o" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"${HIPCC}" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o "${OUT}"
+echo "built ${OUT}"

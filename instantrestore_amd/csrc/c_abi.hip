@@ -1,0 +1,233 @@
+// c_abi.hip - the extern "C" surface declared in include/instantrestore_hip.h.
+// Argument validation, parameter-block construction, launches. No exceptions, no global state
+// other than a thread-local error string and the process-wide tuning variant.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+
+#include "../../include/instantrestore_hip.h"
+#include "ir_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+std::atomic<int> g_variant{0};
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+bool stride_ok(int64_t s) { return s >= 0 && (s % 8) == 0; }  // keeps every head row 16-B aligned
+
+int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_out) {
+  if (a == nullptr) return fail(IR_ERR_INVALID_ARG, "args is NULL");
+  if (a->struct_size != sizeof(ir_shared_attn_args))
+    return fail(IR_ERR_INVALID_ARG, "struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(ir_shared_attn_args));
+  if (a->dtype != IR_DTYPE_F16 && a->dtype != IR_DTYPE_BF16)
+    return fail(IR_ERR_UNSUPPORTED, "dtype %d: only fp16 (0) and bf16 (1) are implemented", a->dtype);
+  if (a->batch <= 0 || a->heads <= 0 || a->len_q <= 0) return fail(IR_ERR_INVALID_ARG, "batch/heads/len_q must be > 0");
+  if (a->n_refs < 0 || a->len_self < 0 || a->len_ref < 0) return fail(IR_ERR_INVALID_ARG, "negative length");
+  const bool inc = (a->flags & IR_FLAG_INCLUDE_SELF) != 0;
+  if (inc && a->len_self <= 0) return fail(IR_ERR_INVALID_ARG, "INCLUDE_SELF with len_self == 0");
+  if (a->n_refs > 0 && a->len_ref <= 0) return fail(IR_ERR_INVALID_ARG, "n_refs > 0 with len_ref == 0");
+  if (!inc && a->n_refs == 0) return fail(IR_ERR_INVALID_ARG, "empty key/value sequence");
+  if (a->q == nullptr || (need_out && a->out == nullptr)) return fail(IR_ERR_INVALID_ARG, "q/out is NULL");
+  if (inc && (a->k_self == nullptr || a->v_self == nullptr)) return fail(IR_ERR_INVALID_ARG, "k_self/v_self is NULL");
+  if (a->n_refs > 0 && (a->k_ref == nullptr || a->v_ref == nullptr)) return fail(IR_ERR_INVALID_ARG, "k_ref/v_ref is NULL");
+  if ((a->adain_a == nullptr) != (a->adain_b == nullptr)) return fail(IR_ERR_INVALID_ARG, "adain_a and adain_b must both be set or both be NULL");
+  if (a->adain_a != nullptr && a->n_refs == 0) return fail(IR_ERR_INVALID_ARG, "AdaIN affine without references");
+  const void* ptrs[] = {a->q, a->k_self, a->v_self, a->k_ref, a->v_ref, a->out, a->adain_a, a->adain_b};
+  for (const void* q : ptrs)
+    if (q != nullptr && !aligned16(q)) return fail(IR_ERR_UNSUPPORTED, "pointer %p is not 16-byte aligned", q);
+  const int64_t strides[] = {a->q_sb, a->q_sl, a->q_sh, a->ks_sb, a->ks_sl, a->ks_sh, a->vs_sb, a->vs_sl, a->vs_sh,
+                             a->kr_sb, a->kr_sn, a->kr_sl, a->kr_sh, a->vr_sb, a->vr_sn, a->vr_sl, a->vr_sh,
+                             a->o_sb, a->o_sl, a->o_sh};
+  for (int64_t s : strides)
+    if (!stride_ok(s)) return fail(IR_ERR_UNSUPPORTED, "stride %lld must be a non-negative multiple of 8 elements", (long long)s);
+
+  memset(p, 0, sizeof(*p));
+  p->q = a->q; p->k_self = a->k_self; p->v_self = a->v_self; p->k_ref = a->k_ref; p->v_ref = a->v_ref;
+  p->aa = a->adain_a; p->ab = a->adain_b; p->out = a->out; p->lse = a->lse;
+  p->q_sb = a->q_sb; p->q_sl = a->q_sl; p->q_sh = a->q_sh;
+  p->ks_sb = a->ks_sb; p->ks_sl = a->ks_sl; p->ks_sh = a->ks_sh;
+  p->vs_sb = a->vs_sb; p->vs_sl = a->vs_sl; p->vs_sh = a->vs_sh;
+  p->kr_sb = a->kr_sb; p->kr_sn = a->kr_sn; p->kr_sl = a->kr_sl; p->kr_sh = a->kr_sh;
+  p->vr_sb = a->vr_sb; p->vr_sn = a->vr_sn; p->vr_sl = a->vr_sl; p->vr_sh = a->vr_sh;
+  p->o_sb = a->o_sb; p->o_sl = a->o_sl; p->o_sh = a->o_sh;
+  p->B = a->batch; p->H = a->heads; p->Lq = a->len_q; p->Ls = a->len_self; p->N = a->n_refs; p->Lr = a->len_ref;
+  p->include_self = inc ? 1 : 0;
+  p->tiles_self = inc ? (a->len_self + IR_KV_TILE - 1) / IR_KV_TILE : 0;
+  p->tiles_ref = a->n_refs > 0 ? (a->len_ref + IR_KV_TILE - 1) / IR_KV_TILE : 0;
+  p->ntiles = p->tiles_self + a->n_refs * p->tiles_ref;
+  p->lkv = (inc ? a->len_self : 0) + a->n_refs * a->len_ref;
+  p->scale = a->scale;
+  p->scale_log2 = a->scale * 1.4426950408889634f;
+  const int64_t blocks = (int64_t)a->batch * a->heads * ((a->len_q + 127) / 128);
+  if (blocks > 0x7fffffffLL) return fail(IR_ERR_UNSUPPORTED, "grid too large");
+  return IR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ir_abi_version(void) { return IR_ABI_VERSION; }
+
+const char* ir_build_info(void) { return "instantrestore_hip gfx950 (CDNA4) hipcc " __VERSION__ " built " __DATE__; }
+
+const char* ir_last_error_string(void) { return g_err; }
+
+int ir_set_attn_variant(int variant) { return g_variant.exchange(variant); }
+
+int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream) {
+  AttnKParams p;
+  const int rc = build_attn_params(args, &p, true);
+  if (rc != IR_OK) return rc;
+  const hipError_t e = ir_launch_shared_attn_fwd(p, args->dtype, g_variant.load(), (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "shared_attn_fwd launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
+int ir_time_shared_attn_fwd(const ir_shared_attn_args* args, int32_t iters, void* stream, float* ms_per_launch) {
+  if (ms_per_launch == nullptr || iters <= 0) return fail(IR_ERR_INVALID_ARG, "iters/ms_per_launch");
+  AttnKParams p;
+  const int rc = build_attn_params(args, &p, true);
+  if (rc != IR_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(IR_ERR_LAUNCH, "hipEventCreate failed");
+  hipError_t e = hipEventRecord(e0, s);
+  for (int i = 0; i < iters && e == hipSuccess; ++i) e = ir_launch_shared_attn_fwd(p, args->dtype, g_variant.load(), s);
+  if (e == hipSuccess) e = hipEventRecord(e1, s);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "timed launch: %s", hipGetErrorString(e));
+  *ms_per_launch = ms / (float)iters;
+  return IR_OK;
+}
+
+int ir_attn_probs(const ir_shared_attn_args* args, void* probs, void* stream) {
+  AttnKParams p;
+  const int rc = build_attn_params(args, &p, false);
+  if (rc != IR_OK) return rc;
+  if (probs == nullptr || args->lse == nullptr) return fail(IR_ERR_INVALID_ARG, "probs/lse is NULL");
+  p.probs = probs;
+  const hipError_t e = ir_launch_attn_probs(p, args->dtype, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "attn_probs launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
+static int adain_nchunk(int32_t len_self, int32_t len_ref) {
+  const int a = (len_self + IR_ADAIN_ROWS - 1) / IR_ADAIN_ROWS;
+  const int b = (len_ref + IR_ADAIN_ROWS - 1) / IR_ADAIN_ROWS;
+  const int m = a > b ? a : b;
+  return m > 0 ? m : 1;
+}
+
+size_t ir_adain_stats_workspace_bytes(int32_t batch, int32_t heads, int32_t len_self, int32_t n_refs, int32_t len_ref) {
+  if (batch <= 0 || heads <= 0 || n_refs < 0) return 0;
+  return (size_t)batch * (size_t)(1 + n_refs) * (size_t)heads * (size_t)adain_nchunk(len_self, len_ref) * 128u * sizeof(float);
+}
+
+int ir_adain_stats(int32_t dtype, int32_t batch, int32_t heads, int32_t len_self, int32_t n_refs, int32_t len_ref,
+                   const void* v_self, int64_t vs_sb, int64_t vs_sl, int64_t vs_sh,
+                   const void* v_ref, int64_t vr_sb, int64_t vr_sn, int64_t vr_sl, int64_t vr_sh,
+                   float eps, float* a, float* b, void* workspace, size_t workspace_bytes, void* stream) {
+  if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (batch <= 0 || heads <= 0 || len_self <= 0 || n_refs <= 0 || len_ref <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (!v_self || !v_ref || !a || !b || !workspace) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  if (!aligned16(v_self) || !aligned16(v_ref)) return fail(IR_ERR_UNSUPPORTED, "v_self/v_ref must be 16-byte aligned");
+  const int64_t st[] = {vs_sb, vs_sl, vs_sh, vr_sb, vr_sn, vr_sl, vr_sh};
+  for (int64_t s : st) if (!stride_ok(s)) return fail(IR_ERR_UNSUPPORTED, "stride %lld must be a non-negative multiple of 8", (long long)s);
+  const size_t need = ir_adain_stats_workspace_bytes(batch, heads, len_self, n_refs, len_ref);
+  if (workspace_bytes < need) return fail(IR_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  AdainKParams p;
+  memset(&p, 0, sizeof(p));
+  p.v_self = v_self; p.v_ref = v_ref;
+  p.vs_sb = vs_sb; p.vs_sl = vs_sl; p.vs_sh = vs_sh;
+  p.vr_sb = vr_sb; p.vr_sn = vr_sn; p.vr_sl = vr_sl; p.vr_sh = vr_sh;
+  p.ws = (float*)workspace; p.a = a; p.b = b;
+  p.B = batch; p.H = heads; p.Ls = len_self; p.N = n_refs; p.Lr = len_ref;
+  p.nchunk = adain_nchunk(len_self, len_ref);
+  p.eps = eps;
+  const hipError_t e = ir_launch_adain_stats(p, dtype, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "adain_stats launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
+int ir_token_stats(int32_t dtype, int32_t batch, int32_t heads, int32_t n_mats, int32_t len,
+                   const void* x, int64_t x_sb, int64_t x_sn, int64_t x_sl, int64_t x_sh,
+                   float* mean, float* std, void* workspace, size_t workspace_bytes, void* stream) {
+  if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (batch <= 0 || heads <= 0 || n_mats <= 0 || len <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (!x || !mean || !std || !workspace) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  if (!aligned16(x)) return fail(IR_ERR_UNSUPPORTED, "x must be 16-byte aligned");
+  const int64_t st[] = {x_sb, x_sn, x_sl, x_sh};
+  for (int64_t s : st) if (!stride_ok(s)) return fail(IR_ERR_UNSUPPORTED, "stride %lld must be a non-negative multiple of 8", (long long)s);
+  const size_t need = ir_adain_stats_workspace_bytes(batch, heads, len, n_mats - 1, len);
+  if (workspace_bytes < need) return fail(IR_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  // matrix 0 of every batch entry plays the "self" role of the partial kernel, 1.. the "refs"
+  AdainKParams p;
+  memset(&p, 0, sizeof(p));
+  p.v_self = x; p.v_ref = (const char*)x + x_sn * 2;
+  p.vs_sb = x_sb; p.vs_sl = x_sl; p.vs_sh = x_sh;
+  p.vr_sb = x_sb; p.vr_sn = x_sn; p.vr_sl = x_sl; p.vr_sh = x_sh;
+  p.ws = (float*)workspace; p.a = mean; p.b = std;
+  p.B = batch; p.H = heads; p.Ls = len; p.N = n_mats - 1; p.Lr = len;
+  p.nchunk = adain_nchunk(len, len);
+  const hipError_t e = ir_launch_token_stats(p, dtype, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "token_stats launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
+int ir_adain_apply(int32_t dtype, int32_t batch, int32_t heads, int32_t n_refs, int32_t len,
+                   const void* x, int64_t x_sb, int64_t x_sn, int64_t x_sl, int64_t x_sh,
+                   const float* a, const float* b,
+                   void* y, int64_t y_sb, int64_t y_sn, int64_t y_sl, int64_t y_sh, void* stream) {
+  if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (batch <= 0 || heads <= 0 || n_refs <= 0 || len <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (!x || !y || !a || !b) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  if (!aligned16(x) || !aligned16(y)) return fail(IR_ERR_UNSUPPORTED, "x/y must be 16-byte aligned");
+  const int64_t st[] = {x_sb, x_sn, x_sl, x_sh, y_sb, y_sn, y_sl, y_sh};
+  for (int64_t s : st) if (!stride_ok(s)) return fail(IR_ERR_UNSUPPORTED, "stride %lld must be a non-negative multiple of 8", (long long)s);
+  AdainApplyKParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.y = y; p.a = a; p.b = b;
+  p.x_sb = x_sb; p.x_sn = x_sn; p.x_sl = x_sl; p.x_sh = x_sh;
+  p.y_sb = y_sb; p.y_sn = y_sn; p.y_sl = y_sl; p.y_sh = y_sh;
+  p.B = batch; p.H = heads; p.N = n_refs; p.L = len;
+  const hipError_t e = ir_launch_adain_apply(p, dtype, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "adain_apply launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
+int ir_zero_invalid_refs(int32_t batch, int32_t heads, int32_t n_refs, int32_t len, const int32_t* valid,
+                         void* k, int64_t k_sb, int64_t k_sn, int64_t k_sl, int64_t k_sh,
+                         void* v, int64_t v_sb, int64_t v_sn, int64_t v_sl, int64_t v_sh, void* stream) {
+  if (batch <= 0 || heads <= 0 || n_refs <= 0 || len <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (!valid || !k || !v) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  if (!aligned16(k) || !aligned16(v)) return fail(IR_ERR_UNSUPPORTED, "k/v must be 16-byte aligned");
+  const int64_t st[] = {k_sb, k_sn, k_sl, k_sh, v_sb, v_sn, v_sl, v_sh};
+  for (int64_t s : st) if (!stride_ok(s)) return fail(IR_ERR_UNSUPPORTED, "stride %lld must be a non-negative multiple of 8", (long long)s);
+  ZeroRefsKParams p;
+  memset(&p, 0, sizeof(p));
+  p.k = k; p.v = v; p.valid = valid;
+  p.k_sb = k_sb; p.k_sn = k_sn; p.k_sl = k_sl; p.k_sh = k_sh;
+  p.v_sb = v_sb; p.v_sn = v_sn; p.v_sl = v_sl; p.v_sh = v_sh;
+  p.B = batch; p.H = heads; p.N = n_refs; p.L = len;
+  const hipError_t e = ir_launch_zero_refs(p, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "zero_refs launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,64 @@
+// ir_common.h - shared device/host helpers for the gfx950 (CDNA4) kernels of instantrestore_amd.
+// Written for MI355X only: 64-wide wavefronts, v_mfma_f32_32x32x16_{bf16,f16}, ds_read_b64_tr_b16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define IR_LDS __attribute__((address_space(3)))
+
+// Element-type traits: the 2-byte storage type T selects the MFMA flavour.
+template <typename T>
+struct ElemTraits;
+
+template <>
+struct ElemTraits<__bf16> {
+  using v8 = bf16x8;
+  using v4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <>
+struct ElemTraits<_Float16> {
+  using v8 = f16x8;
+  using v4 = f16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+// ds_read_b64_tr_b16: within each 16-lane group, lane i receives element (i & 3) of the 8 bytes
+// addressed by lanes (i >> 2) + 4*j, j = 0..3 (a 4x16 -> 16x4 transpose of 16-bit elements).
+static __device__ __forceinline__ s16x4 lds_read_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((IR_LDS s16x4*)(p));
+}
+
+template <typename V8>
+static __device__ __forceinline__ V8 join_tr(s16x4 lo, s16x4 hi) {
+  s16x8 j = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(V8, j);
+}
+
+// XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8): gives every XCD a
+// CONTIGUOUS range of logical work items so blocks that share K/V share an L2.  Bijective for any
+// grid size.  Speed only - correctness never depends on placement.
+static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + slot;
+}
+
+static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

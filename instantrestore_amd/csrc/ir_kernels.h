@@ -1,0 +1,77 @@
+// ir_kernels.h - kernel parameter blocks and host-side launchers (internal; the public
+// interface is include/instantrestore_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define IR_KV_TILE 64          // keys per K/V tile
+#define IR_ADAIN_ROWS 256      // token rows per AdaIN partial-statistics workgroup
+
+// Parameter block of the fused attention kernels (passed by value as the kernel argument).
+struct AttnKParams {
+  const void* q;
+  const void* k_self;
+  const void* v_self;
+  const void* k_ref;
+  const void* v_ref;
+  const float* aa;  // AdaIN scale  (B,N,H,64) or nullptr
+  const float* ab;  // AdaIN shift
+  void* out;
+  float* lse;
+  void* probs;      // attn_probs kernel only
+  int64_t q_sb, q_sl, q_sh;
+  int64_t ks_sb, ks_sl, ks_sh;
+  int64_t vs_sb, vs_sl, vs_sh;
+  int64_t kr_sb, kr_sn, kr_sl, kr_sh;
+  int64_t vr_sb, vr_sn, vr_sl, vr_sh;
+  int64_t o_sb, o_sl, o_sh;
+  int B, H, Lq, Ls, N, Lr;
+  int include_self;   // 0/1
+  int tiles_self;     // ceil(Ls/64) if include_self else 0
+  int tiles_ref;      // ceil(Lr/64)
+  int ntiles;         // include_self*tiles_self + N*tiles_ref
+  int nqb;            // query blocks per (b,h)
+  int lkv;            // include_self*Ls + N*Lr
+  float scale;
+  float scale_log2;   // scale * log2(e)
+};
+
+struct AdainKParams {
+  const void* v_self;
+  const void* v_ref;
+  int64_t vs_sb, vs_sl, vs_sh;
+  int64_t vr_sb, vr_sn, vr_sl, vr_sh;
+  float* ws;          // partial statistics: [B*(1+N)][H][nchunk][2][64] (mean, M2)
+  float* a;
+  float* b;
+  int B, H, Ls, N, Lr;
+  int nchunk;         // max(ceil(Ls/ROWS), ceil(Lr/ROWS))
+  float eps;
+};
+
+struct AdainApplyKParams {
+  const void* x;
+  void* y;
+  const float* a;
+  const float* b;
+  int64_t x_sb, x_sn, x_sl, x_sh;
+  int64_t y_sb, y_sn, y_sl, y_sh;
+  int B, H, N, L;
+};
+
+struct ZeroRefsKParams {
+  void* k;
+  void* v;
+  const int32_t* valid;
+  int64_t k_sb, k_sn, k_sl, k_sh;
+  int64_t v_sb, v_sn, v_sl, v_sh;
+  int B, H, N, L;
+};
+
+// launchers (defined next to their kernels); dtype: 0 = f16, 1 = bf16. Return hipError_t.
+hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s);
+hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, hipStream_t s);
+hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s);
+hipError_t ir_launch_token_stats(const AdainKParams& p, int dtype, hipStream_t s);
+hipError_t ir_launch_adain_apply(const AdainApplyKParams& p, int dtype, hipStream_t s);
+hipError_t ir_launch_zero_refs(const ZeroRefsKParams& p, hipStream_t s);

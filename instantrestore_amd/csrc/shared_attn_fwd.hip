@@ -1,0 +1,315 @@
+// shared_attn_fwd.hip - fused extended self-attention forward for gfx950 (MI355X).
+//
+// Computes, without ever materialising the probability matrix, what
+// face_replace/models/attn_processors.py:232-264 computes with 3+2N head-split copies, N adain()
+// calls, a torch.cat, baddbmm, softmax and bmm:
+//
+//     O = softmax(scale * Q [K_self? ; K_ref_0 ; ... ; K_ref_N-1]^T) [V_self? ; V'_ref_0 ; ...]
+//     V'_ref_n = V_ref_n * a_n + b_n     (AdaIN as a per-channel affine, folded into V staging)
+//
+// Design (CDNA4, 64-wide waves, head_dim 64):
+//   * one workgroup = NW waves = NW*32 query rows of one (batch, head); each wave owns 32 rows;
+//   * the K/V sequence is walked in place as a SEGMENT LIST [self?, ref0, ...] straight out of
+//     the (B,L,C) / (B,N,L,C) activations - 64-key tiles, 128-byte head rows, coalesced 16-B
+//     loads (8 lanes per row), register-staged into double-buffered LDS (32 KiB);
+//   * both GEMMs are issued "swapped" on v_mfma_f32_32x32x16:  S^T = K Q^T  and  O^T = V^T P^T.
+//     That puts a whole probability row (and its output row) in ONE lane pair (l, l^32): the row
+//     max / row sum are in-register reductions plus a single cross-half exchange, the online-
+//     softmax rescale is lane-local, and the exponentiated S registers ARE the B operand of the
+//     PV MFMA - no LDS round trip, no permutes (the key order of the contraction is absorbed
+//     into the order V rows are fetched);
+//   * K tile: XOR-swizzled 16-B slots -> conflict-free ds_read_b128 A-operand fetches;
+//     V tile: row-major with a 64-B half swap -> conflict-free ds_read_b64_tr_b16 transposed
+//     fetches of the V^T A-operand;
+//   * softmax in fp32 in the exp2 domain, scale folded into one FMA; O is rescaled only when a
+//     running max actually moved (exact), otherwise the multiply pass is skipped;
+//   * blockIdx is remapped so the query blocks that share one (b,h)'s K/V sit on one XCD's L2.
+#include "ir_common.h"
+#include "ir_kernels.h"
+
+namespace {
+
+constexpr int KVB = IR_KV_TILE;            // 64 keys per tile
+constexpr int TILE_BYTES = KVB * 64 * 2;   // 8 KiB per K (or V) tile
+
+template <typename T, int NW>
+__global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnKParams p) {
+  using Tr = ElemTraits<T>;
+  using v8 = typename Tr::v8;
+  using v4 = typename Tr::v4;
+  constexpr int NT = NW * 64;          // threads
+  constexpr int QB = NW * 32;          // query rows per workgroup
+  constexpr int CH = (KVB * 8) / NT;   // 16-B chunks per thread per matrix per tile
+  static_assert(CH >= 1, "too many threads for a 64x64 tile");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;   // which 32-lane half
+  const int lq = lane & 31;   // query row within the wave / MFMA column
+
+  // ---- which (batch, head, query block) ---------------------------------------------------
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lin / p.nqb;
+  const int qb = lin - bh * p.nqb;
+  const int b = bh / p.H;
+  const int h = bh - b * p.H;
+
+  // ---- Q fragments: B operand of S^T = K Q^T; lane holds Q[row lq][d = 16ks + 8hi .. +7] -----
+  const int qrow = qb * QB + wid * 32 + lq;
+  const int qrow_c = qrow < p.Lq ? qrow : p.Lq - 1;
+  v8 qf[4];
+  {
+    const T* qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)qrow_c * p.q_sl + (int64_t)h * p.q_sh + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8*)(qp + ks * 16);
+  }
+
+  // ---- staging coordinates (global -> registers -> LDS) ------------------------------------
+  const int slot = tid & 7;  // which 16-B (8 element) slot of the 128-B head row
+  int srow[CH], koff[CH], voff[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int row = (tid >> 3) + c * (NT / 8);
+    srow[c] = row;
+    koff[c] = row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+    voff[c] = row * 128 + ((slot ^ (((row >> 1) & 1) << 2)) << 4);
+  }
+
+  // ---- LDS read offsets ---------------------------------------------------------------------
+  int kread[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kread[ks] = lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4);
+  int vread[2];
+  {
+    const int m = lane & 15, g = (lane >> 4) & 1;
+    const int sw = (m >> 3) & 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+      vread[db] = (4 * hi + (m >> 2)) * 128 + ((db ^ sw) << 6) + 32 * g + 8 * (m & 3);
+  }
+
+  // ---- segment iterator of the prefetch stream (all wave-uniform) --------------------------
+  const int nseg = p.include_self + p.N;
+  const T* sk = nullptr;
+  const T* sv = nullptr;
+  int64_t sksl = 0, svsl = 0;
+  int slen = 0, sntile = 0;
+  bool haff = false;
+  float fa[8], fb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { fa[i] = 1.f; fb[i] = 0.f; }
+
+  auto seg_setup = [&](int s) {
+    if (p.include_self && s == 0) {
+      sk = (const T*)p.k_self + (int64_t)b * p.ks_sb + (int64_t)h * p.ks_sh;
+      sv = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
+      sksl = p.ks_sl; svsl = p.vs_sl; slen = p.Ls; sntile = p.tiles_self; haff = false;
+    } else {
+      const int n = s - p.include_self;
+      sk = (const T*)p.k_ref + (int64_t)b * p.kr_sb + (int64_t)n * p.kr_sn + (int64_t)h * p.kr_sh;
+      sv = (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)n * p.vr_sn + (int64_t)h * p.vr_sh;
+      sksl = p.kr_sl; svsl = p.vr_sl; slen = p.Lr; sntile = p.tiles_ref;
+      haff = (p.aa != nullptr);
+      if (haff) {
+        const int64_t ao = ((int64_t)(b * p.N + n) * p.H + h) * 64 + slot * 8;
+        const f32x4 a0 = *(const f32x4*)(p.aa + ao), a1 = *(const f32x4*)(p.aa + ao + 4);
+        const f32x4 b0 = *(const f32x4*)(p.ab + ao), b1 = *(const f32x4*)(p.ab + ao + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[i] = a0[i]; fa[4 + i] = a1[i]; fb[i] = b0[i]; fb[4 + i] = b1[i]; }
+      }
+    }
+  };
+
+  uint4 kreg[CH], vreg[CH];
+  int seg = 0, t0 = 0;
+
+  auto issue_loads = [&]() -> int {  // loads tile (seg, t0) into registers; returns #valid keys
+    const int key0 = t0 * KVB;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      int r = key0 + srow[c];
+      r = r < slen ? r : slen - 1;  // ragged tail: clamp (those keys are masked below)
+      kreg[c] = *(const uint4*)(sk + (int64_t)r * sksl + slot * 8);
+      vreg[c] = *(const uint4*)(sv + (int64_t)r * svsl + slot * 8);
+    }
+    const int left = slen - key0;
+    return left < KVB ? left : KVB;
+  };
+
+  auto stage_write = [&](int buf) {
+    unsigned char* Kb = smem + buf * (2 * TILE_BYTES);
+    unsigned char* Vb = Kb + TILE_BYTES;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      *(uint4*)(Kb + koff[c]) = kreg[c];
+      uint4 v = vreg[c];
+      if (haff) {  // AdaIN: V' = V*a + b in fp32, one rounding back to T
+        const v8 x = __builtin_bit_cast(v8, v);
+        f32x8 f = __builtin_convertvector(x, f32x8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = __builtin_fmaf(f[i], fa[i], fb[i]);
+        v = __builtin_bit_cast(uint4, __builtin_convertvector(f, v8));
+      }
+      *(uint4*)(Vb + voff[c]) = v;
+    }
+  };
+
+  auto advance = [&]() {
+    if (++t0 == sntile) {
+      t0 = 0;
+      if (++seg < nseg) seg_setup(seg);
+    }
+  };
+
+  // ---- accumulators ----------------------------------------------------------------------
+  f32x16 o0, o1;  // O^T rows d = 32*db + crow(r,hi), column = query lq
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  float m_run = -INFINITY;  // running max of the RAW (unscaled) scores of this lane pair's row
+  float l_run = 0.f;        // this lane's partial row sum (its 32 of every 64 keys)
+  const float c2 = p.scale_log2;
+
+  // ---- prologue ------------------------------------------------------------------------
+  seg_setup(0);
+  int valid_nxt = issue_loads();
+  stage_write(0);
+  advance();
+  __syncthreads();
+  int valid_cur = valid_nxt;
+
+  for (int ti = 0; ti < p.ntiles; ++ti) {
+    const int buf = ti & 1;
+    const bool has_next = (ti + 1 < p.ntiles);
+    if (has_next) valid_nxt = issue_loads();  // HBM/L2 latency hides under this tile's math
+
+    const unsigned char* Kb = smem + buf * (2 * TILE_BYTES);
+    const unsigned char* Vb = Kb + TILE_BYTES;
+
+    // ---- S^T = K Q^T : two 32-key blocks x four 16-wide d steps ---------------------------
+    f32x16 s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const v8 a0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks]);
+      const v8 a1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks]);
+      s0 = Tr::mfma(a0, qf[ks], s0);
+      s1 = Tr::mfma(a1, qf[ks], s1);
+    }
+    // lane (lq,hi) now holds, for query lq, keys crow(r,hi) = (r&3) + 8*(r>>2) + 4*hi (+32 for s1)
+
+    if (valid_cur < KVB) {  // ragged last tile of a segment (wave-uniform branch)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= valid_cur) s0[r] = -INFINITY;
+        if (key + 32 >= valid_cur) s1[r] = -INFINITY;
+      }
+    }
+
+    // ---- online softmax (exp2 domain) -----------------------------------------------------
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float mc = m_new * c2;
+    if (__any(m_new != m_run)) {  // some row's max moved: rescale (exact; skipped otherwise)
+      const float alpha = fast_exp2(m_run * c2 - mc);
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      m_run = m_new;
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = fast_exp2(__builtin_fmaf(s0[r], c2, -mc));
+      s1[r] = fast_exp2(__builtin_fmaf(s1[r], c2, -mc));
+      rs += s0[r] + s1[r];
+    }
+    l_run += rs;
+
+    // P^T fragments (B operand of O^T = V^T P^T): registers 8ks..8ks+7 of key block kb
+    v8 pk[2][2];
+    {
+      const f32x8 p00 = __builtin_shufflevector(s0, s0, 0, 1, 2, 3, 4, 5, 6, 7);
+      const f32x8 p01 = __builtin_shufflevector(s0, s0, 8, 9, 10, 11, 12, 13, 14, 15);
+      const f32x8 p10 = __builtin_shufflevector(s1, s1, 0, 1, 2, 3, 4, 5, 6, 7);
+      const f32x8 p11 = __builtin_shufflevector(s1, s1, 8, 9, 10, 11, 12, 13, 14, 15);
+      pk[0][0] = __builtin_convertvector(p00, v8);
+      pk[0][1] = __builtin_convertvector(p01, v8);
+      pk[1][0] = __builtin_convertvector(p10, v8);
+      pk[1][1] = __builtin_convertvector(p11, v8);
+    }
+
+    // ---- O^T += V^T P^T : A operand = V^T fetched with the LDS transpose read ----------------
+    // k index 8*hi + i of step (kb,ks) is key 32kb + 16ks + 8(i>>2) + 4hi + (i&3): exactly the
+    // key order the P registers already have.
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = (32 * kb + 16 * ks) * 128;
+        const s16x4 a00 = lds_read_tr16(Vb + vread[0] + off);
+        const s16x4 a01 = lds_read_tr16(Vb + vread[0] + off + 8 * 128);
+        const s16x4 a10 = lds_read_tr16(Vb + vread[1] + off);
+        const s16x4 a11 = lds_read_tr16(Vb + vread[1] + off + 8 * 128);
+        o0 = Tr::mfma(join_tr<v8>(a00, a01), pk[kb][ks], o0);
+        o1 = Tr::mfma(join_tr<v8>(a10, a11), pk[kb][ks], o1);
+      }
+    }
+
+    if (has_next) {
+      stage_write(buf ^ 1);
+      advance();
+    }
+    __syncthreads();
+    valid_cur = valid_nxt;
+  }
+
+  // ---- epilogue: normalise, store O (and LSE) ----------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (qrow < p.Lq) {
+    T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 x0, x1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { x0[i] = o0[4 * g4 + i] * inv; x1[i] = o1[4 * g4 + i] * inv; }
+      *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
+      *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
+    }
+    if (p.lse != nullptr && hi == 0)
+      p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_run * p.scale + __logf(l_tot);
+  }
+}
+
+template <typename T, int NW>
+hipError_t launch(const AttnKParams& p0, hipStream_t s) {
+  AttnKParams p = p0;
+  constexpr int QB = NW * 32;
+  p.nqb = (p.Lq + QB - 1) / QB;
+  const int grid = p.B * p.H * p.nqb;
+  hipLaunchKernelGGL((shared_attn_fwd_kernel<T, NW>), dim3(grid), dim3(NW * 64), 0, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// variant: 0 = auto (8 waves for long query axes, 4 waves when that would leave CUs idle),
+//          1 = force 8 waves, 2 = force 4 waves
+hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
+  int nw = 8;
+  if (variant == 2) nw = 4;
+  else if (variant == 0) {
+    const long blocks8 = (long)p.B * p.H * ((p.Lq + 255) / 256);
+    if (blocks8 < 256 || p.Lq <= 128) nw = 4;
+  }
+  if (dtype == 1) return nw == 8 ? launch<__bf16, 8>(p, s) : launch<__bf16, 4>(p, s);
+  return nw == 8 ? launch<_Float16, 8>(p, s) : launch<_Float16, 4>(p, s);
+}

@@ -1,0 +1,54 @@
+"""Reference K/V harvest: the path-relevant part of
+``Pix2Pix_Turbo.get_conditioning_keys_values`` (face_replace/models/pix2pix_turbo.py:260-275).
+
+After the frozen reference UNet has run over the ``B*N`` reference latents, each of its nine
+decoder self-attention processors (:class:`AttnProcessor`, selected by EXACT type like the
+reference does at :260) holds ``keys`` / ``values`` of shape ``(B*N, L, C)``.  They are
+re-viewed as ``(B, N, L, C)`` - a view, never a copy - the references ``n >= valid_indices[b]``
+are zero-filled in place (zeroed, NOT masked: they keep their exp(0) softmax weight, :269-273)
+by one HIP launch per layer instead of the reference's Python ``layers x samples`` loop, and the
+processors are reset (:275).  The two lists are what the main UNet receives as
+``cross_attention_kwargs={'ref_keys': ..., 'ref_values': ...}``.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+
+from . import attn_processors as _ap
+from . import ops as _ops
+
+
+def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int],
+                         reset: bool = True) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    procs = [p for p in original_unet.attn_processors.values() if type(p) in [_ap.AttnProcessor]]
+    if not procs:
+        raise RuntimeError("no AttnProcessor on this UNet: call register_attention_processor_kv_unet first")
+    keys, values = [], []
+    for p in procs:
+        if p.keys is None or p.values is None:
+            raise RuntimeError("reference UNet has not been run since the last reset()")
+        k = p.keys.reshape(-1, n_refs, p.keys.shape[1], p.keys.shape[2])
+        v = p.values.reshape(-1, n_refs, p.values.shape[1], p.values.shape[2])
+        keys.append(k)
+        values.append(v)
+    valid = torch.as_tensor(valid_indices)
+    if bool((valid < n_refs).any()):
+        heads = keys[0].shape[-1] // _ops.HEAD_DIM
+        for k, v in zip(keys, values):
+            _ops.zero_invalid_refs(k, v, valid, heads=k.shape[-1] // _ops.HEAD_DIM)
+        del heads
+    if reset:
+        for p in procs:
+            p.reset()
+    return keys, values
+
+
+def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, timestep, encoder_hidden_states,
+                                 n_refs: int, valid_indices: Sequence[int]):
+    """Run the frozen reference UNet on the (already encoded and noised) reference latents
+    ``(B*N, 4, S, S)`` and harvest.  VAE encode/decode, the scheduler and the caption encoder
+    around it (pix2pix_turbo.py:244-257, 277-278) are stock PyTorch and out of scope."""
+    original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
+    return harvest_reference_kv(original_unet, n_refs, valid_indices)

@@ -1,0 +1,253 @@
+"""Tensor-level entry points of the HIP hot path.
+
+Thin, allocation-only wrappers: they check devices / dtypes / strides, allocate outputs with
+torch (device memory and streams are PyTorch-ROCm plumbing) and hand raw pointers, element
+strides and the current HIP stream to the C ABI (``include/instantrestore_hip.h``).  Nothing
+here computes anything, and nothing falls back to torch math: a CPU tensor or a missing
+library is an error.
+
+Layouts are the reference's own, consumed IN PLACE (no head-split copies, no ``cat``):
+``q, k_self, v_self``: ``(B, L, H*64)``; ``ref_k, ref_v``: ``(B, N, Lr, H*64)`` exactly as
+``Pix2Pix_Turbo.get_conditioning_keys_values`` hands them over (pix2pix_turbo.py:265-266).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+HEAD_DIM = 64
+ADAIN_EPS = 1e-5  # attn_processors.py:10,245
+
+_DT = {torch.float16: _lib.IR_DTYPE_F16, torch.bfloat16: _lib.IR_DTYPE_BF16}
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(
+            f"the fused HIP path computes in fp16/bf16 (got {t.dtype}); run the model under "
+            "torch.autocast (as face_replace/inference/test.py:83 does) or cast it to bf16/fp16"
+        ) from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*ts: Optional[torch.Tensor]) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "instantrestore_amd ops run on the MI355X only; got a CPU tensor "
+                "(there is no CPU fallback - the CPU restatement lives in oracle/ and is test-only)"
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def _tok(t: torch.Tensor, heads: int, name: str) -> torch.Tensor:
+    """(B, L, H*64) view usable in place; falls back to .contiguous() only for exotic strides."""
+    if t.dim() != 3 or t.shape[-1] != heads * HEAD_DIM:
+        raise ValueError(f"{name}: expected (B, L, {heads * HEAD_DIM}), got {tuple(t.shape)}")
+    if t.stride(-1) != 1 or t.stride(0) % 8 or t.stride(1) % 8 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def _ref(t: torch.Tensor, heads: int, name: str) -> torch.Tensor:
+    if t.dim() != 4 or t.shape[-1] != heads * HEAD_DIM:
+        raise ValueError(f"{name}: expected (B, N, L, {heads * HEAD_DIM}), got {tuple(t.shape)}")
+    if t.stride(-1) != 1 or any(t.stride(i) % 8 for i in range(3)) or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse):
+    a = _lib.SharedAttnArgs()
+    a.struct_size = C.sizeof(_lib.SharedAttnArgs)
+    a.dtype = _dtype_code(q)
+    a.flags = _lib.IR_FLAG_INCLUDE_SELF if include_self else 0
+    a.batch, a.len_q, _ = q.shape
+    a.heads = heads
+    a.scale = float(scale)
+    a.q = q.data_ptr()
+    a.q_sb, a.q_sl, a.q_sh = q.stride(0), q.stride(1), HEAD_DIM
+    if include_self:
+        a.len_self = k_self.shape[1]
+        a.k_self, a.v_self = k_self.data_ptr(), v_self.data_ptr()
+        a.ks_sb, a.ks_sl, a.ks_sh = k_self.stride(0), k_self.stride(1), HEAD_DIM
+        a.vs_sb, a.vs_sl, a.vs_sh = v_self.stride(0), v_self.stride(1), HEAD_DIM
+    if ref_k is not None:
+        a.n_refs, a.len_ref = ref_k.shape[1], ref_k.shape[2]
+        a.k_ref, a.v_ref = ref_k.data_ptr(), ref_v.data_ptr()
+        a.kr_sb, a.kr_sn, a.kr_sl, a.kr_sh = ref_k.stride(0), ref_k.stride(1), ref_k.stride(2), HEAD_DIM
+        a.vr_sb, a.vr_sn, a.vr_sl, a.vr_sh = ref_v.stride(0), ref_v.stride(1), ref_v.stride(2), HEAD_DIM
+    if adain is not None:
+        a.adain_a, a.adain_b = adain[0].data_ptr(), adain[1].data_ptr()
+    if out is not None:
+        a.out = out.data_ptr()
+        a.o_sb, a.o_sl, a.o_sh = out.stride(0), out.stride(1), HEAD_DIM
+    if lse is not None:
+        a.lse = lse.data_ptr()
+    return a
+
+
+def _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain):
+    _need_gpu(q, k_self, v_self, ref_k, ref_v)
+    q = _tok(q, heads, "q")
+    if (ref_k is None) != (ref_v is None):
+        raise ValueError("ref_k and ref_v must be given together")
+    if ref_k is None and not include_self:
+        raise ValueError("no references and include_self=False: empty key/value sequence")
+    if include_self:
+        k_self, v_self = _tok(k_self, heads, "k_self"), _tok(v_self, heads, "v_self")
+        if k_self.shape != v_self.shape or k_self.shape[0] != q.shape[0]:
+            raise ValueError("k_self / v_self shape mismatch")
+    if ref_k is not None:
+        ref_k, ref_v = _ref(ref_k, heads, "ref_k"), _ref(ref_v, heads, "ref_v")
+        if ref_k.shape != ref_v.shape or ref_k.shape[0] != q.shape[0]:
+            raise ValueError("ref_k / ref_v shape mismatch")
+    for t in (k_self if include_self else None, v_self if include_self else None, ref_k, ref_v):
+        if t is not None and t.dtype != q.dtype:
+            raise TypeError(f"mixed dtypes on the fused path: q is {q.dtype}, a K/V tensor is {t.dtype}")
+    if adain is not None:
+        if ref_k is None:
+            raise ValueError("AdaIN affine given without references")
+        B, N = ref_k.shape[:2]
+        for t in adain:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != B * N * heads * HEAD_DIM:
+                raise ValueError("adain (a, b) must be contiguous fp32 of shape (B, N, H, 64)")
+    return q, k_self, v_self, ref_k, ref_v
+
+
+def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
+                     include_self: bool = True, adain: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                     return_lse: bool = False):
+    """Fused extended self-attention (``ir_shared_attn_fwd``).
+
+    Returns ``out`` (B, Lq, H*64) in q's dtype [and ``lse`` (B, H, Lq) fp32].  ``adain`` is the
+    (a, b) pair from :func:`adain_stats`; the reference-V renormalisation happens inside the
+    kernel's V staging.
+    """
+    q, k_self, v_self, ref_k, ref_v = _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain)
+    out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=q.dtype, device=q.device)
+    lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if return_lse else None
+    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse)
+    _lib.check(_lib.lib().ir_shared_attn_fwd(C.byref(args), _stream()), "ir_shared_attn_fwd")
+    return (out, lse) if return_lse else out
+
+
+def time_shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
+                          include_self: bool = True, adain=None, iters: int = 10) -> float:
+    """Average ms per launch measured with HIP events on the launch stream (``bench.py``)."""
+    q, k_self, v_self, ref_k, ref_v = _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain)
+    out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=q.dtype, device=q.device)
+    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, None)
+    ms = C.c_float(0.0)
+    _lib.check(_lib.lib().ir_time_shared_attn_fwd(C.byref(args), int(iters), _stream(), C.byref(ms)),
+               "ir_time_shared_attn_fwd")
+    return float(ms.value)
+
+
+def attn_probs(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True) -> torch.Tensor:
+    """Materialise ``attention_probs`` (B, H, Lq, Lkv) from the LSE of the fused forward
+    (``ir_attn_probs``; the ``save_self_attentions`` dump path, attn_processors.py:258-261)."""
+    v_dummy = k_self
+    r_dummy = ref_k
+    q, k_self, _, ref_k, _ = _prep(q, k_self, v_dummy, ref_k, r_dummy, heads, include_self, None)
+    B, Lq, _ = q.shape
+    lkv = (k_self.shape[1] if include_self else 0) + (ref_k.shape[1] * ref_k.shape[2] if ref_k is not None else 0)
+    if lse.dtype != torch.float32 or not lse.is_contiguous() or tuple(lse.shape) != (B, heads, Lq):
+        raise ValueError("lse must be contiguous fp32 (B, H, Lq)")
+    probs = torch.empty((B, heads, Lq, lkv), dtype=q.dtype, device=q.device)
+    args = _fill_args(q, k_self, k_self, ref_k, ref_k, heads, scale, include_self, None, None, lse)
+    _lib.check(_lib.lib().ir_attn_probs(C.byref(args), probs.data_ptr(), _stream()), "ir_attn_probs")
+    return probs
+
+
+def adain_stats(v_self: torch.Tensor, ref_v: torch.Tensor, *, heads: int, eps: float = ADAIN_EPS):
+    """AdaIN as a per-(b, n, head, channel) affine ``x*a + b`` (``ir_adain_stats``).
+
+    ``v_self`` (B, L, H*64) supplies the style statistics, ``ref_v`` (B, N, Lr, H*64) the content
+    statistics (attn_processors.py:9-10, 244-245: token axis, unbiased std, eps on both)."""
+    _need_gpu(v_self, ref_v)
+    v_self, ref_v = _tok(v_self, heads, "v_self"), _ref(ref_v, heads, "ref_v")
+    if v_self.dtype != ref_v.dtype:
+        raise TypeError("v_self / ref_v dtype mismatch")
+    B, Ls, _ = v_self.shape
+    _, N, Lr, _ = ref_v.shape
+    L = _lib.lib()
+    nbytes = L.ir_adain_stats_workspace_bytes(B, heads, Ls, N, Lr)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=v_self.device)
+    a = torch.empty((B, N, heads, HEAD_DIM), dtype=torch.float32, device=v_self.device)
+    b = torch.empty_like(a)
+    rc = L.ir_adain_stats(_dtype_code(v_self), B, heads, Ls, N, Lr,
+                          v_self.data_ptr(), v_self.stride(0), v_self.stride(1), HEAD_DIM,
+                          ref_v.data_ptr(), ref_v.stride(0), ref_v.stride(1), ref_v.stride(2), HEAD_DIM,
+                          float(eps), a.data_ptr(), b.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _lib.check(rc, "ir_adain_stats")
+    return a, b
+
+
+def token_stats(x: torch.Tensor, *, heads: int):
+    """mean and unbiased std over the token axis of x (B, M, L, H*64) -> two fp32 (B, M, H, 64)
+    tensors (``ir_token_stats``)."""
+    _need_gpu(x)
+    x = _ref(x, heads, "x")
+    B, M, Lx, _ = x.shape
+    L = _lib.lib()
+    nbytes = L.ir_adain_stats_workspace_bytes(B, heads, Lx, M - 1, Lx)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    mean = torch.empty((B, M, heads, HEAD_DIM), dtype=torch.float32, device=x.device)
+    std = torch.empty_like(mean)
+    rc = L.ir_token_stats(_dtype_code(x), B, heads, M, Lx,
+                          x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), HEAD_DIM,
+                          mean.data_ptr(), std.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _lib.check(rc, "ir_token_stats")
+    return mean, std
+
+
+def adain_apply(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, *, heads: int) -> torch.Tensor:
+    """``y = x*a + b`` over (B, N, L, H*64) (``ir_adain_apply``; op-level parity, ``adain()``)."""
+    _need_gpu(x, a, b)
+    x = _ref(x, heads, "x")
+    B, N, Lx, _ = x.shape
+    y = torch.empty_like(x, memory_format=torch.contiguous_format)
+    rc = _lib.lib().ir_adain_apply(_dtype_code(x), B, heads, N, Lx,
+                                   x.data_ptr(), x.stride(0), x.stride(1), x.stride(2), HEAD_DIM,
+                                   a.data_ptr(), b.data_ptr(),
+                                   y.data_ptr(), y.stride(0), y.stride(1), y.stride(2), HEAD_DIM, _stream())
+    _lib.check(rc, "ir_adain_apply")
+    return y
+
+
+def zero_invalid_refs(k: torch.Tensor, v: torch.Tensor, valid_indices: torch.Tensor, *, heads: int) -> None:
+    """In place: zero K and V of references ``n >= valid_indices[b]`` (``ir_zero_invalid_refs``;
+    pix2pix_turbo.py:269-273 - zeroed, not masked)."""
+    _need_gpu(k, v)
+    if k.dim() != 4 or k.shape != v.shape or k.stride(-1) != 1 or v.stride(-1) != 1:
+        raise ValueError("k, v must be (B, N, L, H*64) views with a contiguous channel axis")
+    B, N, L, _ = k.shape
+    valid = torch.as_tensor(valid_indices).to(device=k.device, dtype=torch.int32).contiguous()
+    if valid.numel() != B:
+        raise ValueError("valid_indices must have one entry per batch element")
+    rc = _lib.lib().ir_zero_invalid_refs(B, heads, N, L, valid.data_ptr(),
+                                         k.data_ptr(), k.stride(0), k.stride(1), k.stride(2), HEAD_DIM,
+                                         v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), HEAD_DIM, _stream())
+    _lib.check(rc, "ir_zero_invalid_refs")
+
+
+def set_attn_variant(variant: int) -> int:
+    """tuning hook for benchmarks/tests (0 = auto, 1 = 8-wave, 2 = 4-wave workgroups)"""
+    return _lib.lib().ir_set_attn_variant(int(variant))

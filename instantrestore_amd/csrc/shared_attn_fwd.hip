@@ -5,24 +5,34 @@
 // calls, a torch.cat, baddbmm, softmax and bmm:
 //
 //     O = softmax(scale * Q [K_self? ; K_ref_0 ; ... ; K_ref_N-1]^T) [V_self? ; V'_ref_0 ; ...]
-//     V'_ref_n = V_ref_n * a_n + b_n     (AdaIN as a per-channel affine, folded into V staging)
+//     V'_ref_n = V_ref_n * a_n + b_n            (AdaIN as a per-channel affine)
 //
 // Design (CDNA4, 64-wide waves, head_dim 64):
 //   * one workgroup = NW waves = NW*32 query rows of one (batch, head); each wave owns 32 rows;
 //   * the K/V sequence is walked in place as a SEGMENT LIST [self?, ref0, ...] straight out of
 //     the (B,L,C) / (B,N,L,C) activations - 64-key tiles, 128-byte head rows, coalesced 16-B
-//     loads (8 lanes per row), register-staged into double-buffered LDS (32 KiB);
+//     buffer loads (8 lanes per row; rows past a ragged segment end are zero-filled by the
+//     descriptor's bounds check), register-staged into double-buffered LDS (32 KiB);
 //   * both GEMMs are issued "swapped" on v_mfma_f32_32x32x16:  S^T = K Q^T  and  O^T = V^T P^T.
 //     That puts a whole probability row (and its output row) in ONE lane pair (l, l^32): the row
-//     max / row sum are in-register reductions plus a single cross-half exchange, the online-
-//     softmax rescale is lane-local, and the exponentiated S registers ARE the B operand of the
-//     PV MFMA - no LDS round trip, no permutes (the key order of the contraction is absorbed
-//     into the order V rows are fetched);
+//     max is an in-register v_max3 chain plus one v_permlane32_swap, the online-softmax rescale
+//     is lane-local, and the exponentiated S registers ARE the B operand of the PV MFMA - no LDS
+//     round trip, no permutes (the key order of the contraction is absorbed into the order V rows
+//     are fetched);
+//   * D = 64 makes this kernel VALU-issue bound, not MFMA bound (one exp + ~3 VALU per score
+//     against 256 MFMA flops), so everything that can leave the VALU port does:
+//       - row sums ride on the matrix pipe: a constant "ones" A-fragment appended as a 65th
+//         V^T row gives l = P 1 from 4 extra MFMAs per tile instead of 32 v_add per lane;
+//       - the AdaIN affine is NOT applied to V tiles; it is folded algebraically per segment:
+//         O += (P_seg V_seg) o a_seg + rowsum(P_seg) b_seg  at each segment boundary (two FMAs
+//         per accumulator per SEGMENT instead of per-tile unpack/FMA/pack work), so the
+//         renormalised V is never formed anywhere;
+//       - scale-and-subtract runs as packed v_pk_fma_f32; maxima as v_max3;
 //   * K tile: XOR-swizzled 16-B slots -> conflict-free ds_read_b128 A-operand fetches;
 //     V tile: row-major with a 64-B half swap -> conflict-free ds_read_b64_tr_b16 transposed
-//     fetches of the V^T A-operand;
-//   * softmax in fp32 in the exp2 domain, scale folded into one FMA; O is rescaled only when a
-//     running max actually moved (exact), otherwise the multiply pass is skipped;
+//     fetches of the V^T A-operand (SQ_LDS_BANK_CONFLICT = 0 measured);
+//   * softmax in fp32 in the exp2 domain; accumulators are rescaled only when a running max
+//     actually moved (exact), otherwise the multiply pass is skipped;
 //   * blockIdx is remapped so the query blocks that share one (b,h)'s K/V sit on one XCD's L2.
 #include "ir_common.h"
 #include "ir_kernels.h"
@@ -32,7 +42,10 @@ namespace {
 constexpr int KVB = IR_KV_TILE;            // 64 keys per tile
 constexpr int TILE_BYTES = KVB * 64 * 2;   // 8 KiB per K (or V) tile
 
-template <typename T, int NW>
+// ABL: ablation bits for timing experiments only (results are WRONG when non-zero):
+//   1 = no staging (no global loads / LDS writes / barriers), 2 = no softmax max/exp,
+//   4 = no LDS fragment reads (constant operands)
+template <typename T, int NW, bool FOLD, int ABL = 0>
 __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
@@ -66,6 +79,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8*)(qp + ks * 16);
   }
+  // "ones" A-fragment: row 0 of a virtual third 32-row block of V^T is all ones, rows 1..31 zero
+  v8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (lq == 0) ? (T)1.0f : (T)0.0f;
 
   // ---- staging coordinates (global -> registers -> LDS) ------------------------------------
   const int slot = tid & 7;  // which 16-B (8 element) slot of the 128-B head row
@@ -92,41 +109,27 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
   }
 
   // ---- segment iterator of the prefetch stream (all wave-uniform) --------------------------
-  // K/V rows are fetched with buffer loads: one resource descriptor per (segment, tensor) whose
-  // num_records ends right after the last valid head row, so rows past a ragged segment end read
-  // as zeros in hardware (those keys are masked to -inf below) and no address is ever clamped.
   const int nseg = p.include_self + p.N;
   __amdgpu_buffer_rsrc_t krs, vrs;
   int kstep = 0, vstep = 0;  // bytes per 64-key tile
-  int slen = 0, sntile = 0;
-  bool haff = false;
-  float fa[8], fb[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { fa[i] = 1.f; fb[i] = 0.f; }
+  int sntile = 0;
   unsigned kvo[CH], vvo[CH];  // per-thread byte offsets of this thread's chunks inside the segment
 
   auto seg_setup = [&](int s) {
     const T* sk;
     const T* sv;
-    int ksl_b, vsl_b;
+    int ksl_b, vsl_b, slen;
     if (p.include_self && s == 0) {
       sk = (const T*)p.k_self + (int64_t)b * p.ks_sb + (int64_t)h * p.ks_sh;
       sv = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
-      ksl_b = (int)p.ks_sl * 2; vsl_b = (int)p.vs_sl * 2; slen = p.Ls; sntile = p.tiles_self; haff = false;
+      ksl_b = (int)p.ks_sl * 2; vsl_b = (int)p.vs_sl * 2; slen = p.Ls; sntile = p.tiles_self;
     } else {
       const int n = s - p.include_self;
       sk = (const T*)p.k_ref + (int64_t)b * p.kr_sb + (int64_t)n * p.kr_sn + (int64_t)h * p.kr_sh;
       sv = (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)n * p.vr_sn + (int64_t)h * p.vr_sh;
       ksl_b = (int)p.kr_sl * 2; vsl_b = (int)p.vr_sl * 2; slen = p.Lr; sntile = p.tiles_ref;
-      haff = (p.aa != nullptr);
-      if (haff) {
-        const int64_t ao = ((int64_t)(b * p.N + n) * p.H + h) * 64 + slot * 8;
-        const f32x4 a0 = *(const f32x4*)(p.aa + ao), a1 = *(const f32x4*)(p.aa + ao + 4);
-        const f32x4 b0 = *(const f32x4*)(p.ab + ao), b1 = *(const f32x4*)(p.ab + ao + 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { fa[i] = a0[i]; fa[4 + i] = a1[i]; fb[i] = b0[i]; fb[4 + i] = b1[i]; }
-      }
     }
+    // num_records ends right after the last valid head row: later rows read as zeros
     krs = __builtin_amdgcn_make_buffer_rsrc((void*)sk, 0, (slen - 1) * ksl_b + 128, 0x00020000);
     vrs = __builtin_amdgcn_make_buffer_rsrc((void*)sv, 0, (slen - 1) * vsl_b + 128, 0x00020000);
     kstep = KVB * ksl_b;
@@ -141,7 +144,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
   u32x4 kreg[CH], vreg[CH];
   int seg = 0, t0 = 0;
 
-  auto issue_loads = [&]() -> int {  // loads tile (seg, t0) into registers; returns #valid keys
+  auto issue_loads = [&]() {
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       kreg[c] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvo[c], 0, 0);
@@ -149,28 +152,16 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
       kvo[c] += kstep;
       vvo[c] += vstep;
     }
-    const int left = slen - t0 * KVB;
-    return left < KVB ? left : KVB;
   };
-
   auto stage_write = [&](int buf) {
     unsigned char* Kb = smem + buf * (2 * TILE_BYTES);
     unsigned char* Vb = Kb + TILE_BYTES;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       *(u32x4*)(Kb + koff[c]) = kreg[c];
-      u32x4 v = vreg[c];
-      if (haff) {  // AdaIN: V' = V*a + b in fp32, one rounding back to T
-        const v8 x = __builtin_bit_cast(v8, v);
-        f32x8 f = __builtin_convertvector(x, f32x8);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f[i] = __builtin_fmaf(f[i], fa[i], fb[i]);
-        v = __builtin_bit_cast(u32x4, __builtin_convertvector(f, v8));
-      }
-      *(u32x4*)(Vb + voff[c]) = v;
+      *(u32x4*)(Vb + voff[c]) = vreg[c];
     }
   };
-
   auto advance = [&]() {
     if (++t0 == sntile) {
       t0 = 0;
@@ -179,25 +170,38 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
   };
 
   // ---- accumulators ----------------------------------------------------------------------
-  f32x16 o0, o1;  // O^T rows d = 32*db + crow(r,hi), column = query lq
+  // o0/o1: O^T of the CURRENT segment, rows d = 32*db + crow(r,hi), column = query lq
+  // o2   : ones block; o2[0] of the hi=0 lane = row sum of the current segment
+  // ot0/ot1/l_tot (FOLD only): everything folded so far, AdaIN affine applied
+  f32x16 o0, o1, o2, ot0, ot1;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; o2[r] = 0.f; ot0[r] = 0.f; ot1[r] = 0.f; }
+  float l_tot = 0.f;
   float m_run = -INFINITY;  // running max of the RAW (unscaled) scores of this lane pair's row
-  float l_run = 0.f;        // this lane's partial row sum (its 32 of every 64 keys)
   const float c2 = p.scale_log2;
+
+  // compute-stream position (lags the prefetch stream by one tile)
+  int cseg = 0, ct0 = 0;
+  int c_ntile = (p.include_self ? p.tiles_self : p.tiles_ref);
+  int c_len = (p.include_self ? p.Ls : p.Lr);
 
   // ---- prologue ------------------------------------------------------------------------
   seg_setup(0);
-  int valid_nxt = issue_loads();
+  issue_loads();
   stage_write(0);
   advance();
+  // Retire the Q-fragment loads HERE.  hipcc's waitcnt pass otherwise carries them as "maybe
+  // outstanding" into the loop and guards the first use of qf[] in every iteration with a
+  // vmcnt(1)/vmcnt(0) that also drains the K/V prefetch issued a few instructions earlier - a
+  // full memory latency at the top of every tile (found in the .s; the prefetch was dead).
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks]));
   __syncthreads();
-  int valid_cur = valid_nxt;
 
   for (int ti = 0; ti < p.ntiles; ++ti) {
     const int buf = ti & 1;
     const bool has_next = (ti + 1 < p.ntiles);
-    if (has_next) valid_nxt = issue_loads();  // HBM/L2 latency hides under this tile's math
+    if (has_next && !(ABL & 1)) issue_loads();  // HBM/L2 latency hides under this tile's math
 
     const unsigned char* Kb = smem + buf * (2 * TILE_BYTES);
     const unsigned char* Vb = Kb + TILE_BYTES;
@@ -208,13 +212,14 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const v8 a0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks]);
-      const v8 a1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks]);
+      const v8 a0 = (ABL & 4) ? qf[(ks + 1) & 3] : *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks]);
+      const v8 a1 = (ABL & 4) ? qf[(ks + 2) & 3] : *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks]);
       s0 = Tr::mfma(a0, qf[ks], s0);
       s1 = Tr::mfma(a1, qf[ks], s1);
     }
     // lane (lq,hi) now holds, for query lq, keys crow(r,hi) = (r&3) + 8*(r>>2) + 4*hi (+32 for s1)
 
+    const int valid_cur = c_len - ct0 * KVB;
     if (valid_cur < KVB) {  // ragged last tile of a segment (wave-uniform branch)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -229,6 +234,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
     // only for instructions it can see, so the 12 wait states an 8-pass MFMA result needs are
     // spelled out here, tied to both accumulators so nothing that reads them moves above it.
     asm volatile("s_nop 7\n\ts_nop 4" : "+v"(s0), "+v"(s1));
+    if (!(ABL & 2)) {
     // two independent v_max3 chains (one per key block), then one cross-half exchange:
     // permlane32_swap(x, x) leaves {own, partner} (in either order) in the two results
     float mxa = max3(s0[0], s0[1], s0[2]);
@@ -247,19 +253,30 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
     const float mc = m_new * c2;
     if (__any(m_new != m_run)) {  // some row's max moved: rescale (exact; skipped otherwise)
       const float alpha = fast_exp2(m_run * c2 - mc);
-      l_run *= alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      o2[0] *= alpha;
+      if (FOLD) {
+        l_tot *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ot0[r] *= alpha; ot1[r] *= alpha; }
+      }
       m_run = m_new;
     }
-    float rs = 0.f;
+    {
+      const f32x2 cc = {c2, c2};
+      const f32x2 nm = {-mc, -mc};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[r] = fast_exp2(__builtin_fmaf(s0[r], c2, -mc));
-      s1[r] = fast_exp2(__builtin_fmaf(s1[r], c2, -mc));
-      rs += s0[r] + s1[r];
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 t0v = {s0[r], s0[r + 1]};
+        f32x2 t1v = {s1[r], s1[r + 1]};
+        t0v = __builtin_elementwise_fma(t0v, cc, nm);  // v_pk_fma_f32
+        t1v = __builtin_elementwise_fma(t1v, cc, nm);
+        s0[r] = fast_exp2(t0v[0]); s0[r + 1] = fast_exp2(t0v[1]);
+        s1[r] = fast_exp2(t1v[0]); s1[r + 1] = fast_exp2(t1v[1]);
+      }
     }
-    l_run += rs;
+    }  // !(ABL & 2)
 
     // P^T fragments (B operand of O^T = V^T P^T): registers 8ks..8ks+7 of key block kb
     v8 pk[2][2];
@@ -276,68 +293,133 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_kernel(const AttnK
 
     // ---- O^T += V^T P^T : A operand = V^T fetched with the LDS transpose read ----------------
     // k index 8*hi + i of step (kb,ks) is key 32kb + 16ks + 8(i>>2) + 4hi + (i&3): exactly the
-    // key order the P registers already have.
+    // key order the P registers already have.  The third MFMA of every step multiplies the
+    // constant ones fragment: its row 0 accumulates the row sum of the (rounded) P.
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int off = (32 * kb + 16 * ks) * 128;
-        const s16x4 a00 = lds_read_tr16(Vb + vread[0] + off);
-        const s16x4 a01 = lds_read_tr16(Vb + vread[0] + off + 8 * 128);
-        const s16x4 a10 = lds_read_tr16(Vb + vread[1] + off);
-        const s16x4 a11 = lds_read_tr16(Vb + vread[1] + off + 8 * 128);
-        o0 = Tr::mfma(join_tr<v8>(a00, a01), pk[kb][ks], o0);
-        o1 = Tr::mfma(join_tr<v8>(a10, a11), pk[kb][ks], o1);
+        o2 = Tr::mfma(ones, pk[kb][ks], o2);
+        if (ABL & 4) {
+          o0 = Tr::mfma(qf[kb + ks], pk[kb][ks], o0);
+          o1 = Tr::mfma(qf[3 - kb - ks], pk[kb][ks], o1);
+        } else {
+          const s16x4 a00 = lds_read_tr16(Vb + vread[0] + off);
+          const s16x4 a01 = lds_read_tr16(Vb + vread[0] + off + 8 * 128);
+          const s16x4 a10 = lds_read_tr16(Vb + vread[1] + off);
+          const s16x4 a11 = lds_read_tr16(Vb + vread[1] + off + 8 * 128);
+          o0 = Tr::mfma(join_tr<v8>(a00, a01), pk[kb][ks], o0);
+          o1 = Tr::mfma(join_tr<v8>(a10, a11), pk[kb][ks], o1);
+        }
       }
     }
 
-    if (has_next) {
-      stage_write(buf ^ 1);
-      advance();
+    // ---- segment boundary of the compute stream: fold the AdaIN affine ----------------------
+    if (++ct0 == c_ntile) {
+      if (FOLD) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o2[0]), __float_as_uint(o2[0]), false, false);
+        const float lseg = __uint_as_float(sw[0]);  // row sum from the hi=0 lane, in both halves
+        l_tot += lseg;
+        const bool is_ref = !(p.include_self && cseg == 0);
+        if (is_ref && p.aa != nullptr) {
+          const int n = cseg - p.include_self;
+          const int64_t ao = ((int64_t)(b * p.N + n) * p.H + h) * 64 + 4 * hi;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 a0 = *(const f32x4*)(p.aa + ao + 8 * g4), a1 = *(const f32x4*)(p.aa + ao + 32 + 8 * g4);
+            const f32x4 b0 = *(const f32x4*)(p.ab + ao + 8 * g4), b1 = *(const f32x4*)(p.ab + ao + 32 + 8 * g4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              ot0[4 * g4 + i] = __builtin_fmaf(o0[4 * g4 + i], a0[i], __builtin_fmaf(lseg, b0[i], ot0[4 * g4 + i]));
+              ot1[4 * g4 + i] = __builtin_fmaf(o1[4 * g4 + i], a1[i], __builtin_fmaf(lseg, b1[i], ot1[4 * g4 + i]));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { ot0[r] += o0[r]; ot1[r] += o1[r]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+        o2[0] = 0.f;
+      }
+      ct0 = 0;
+      ++cseg;
+      c_ntile = p.tiles_ref;
+      c_len = p.Lr;
     }
-    __syncthreads();
-    valid_cur = valid_nxt;
+
+    if (!(ABL & 1)) {
+      if (has_next) {
+        stage_write(buf ^ 1);
+        advance();
+      }
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: normalise, store O (and LSE) ----------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
+  float l_fin;
+  if (FOLD) {
+    l_fin = l_tot;
+  } else {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(o2[0]), __float_as_uint(o2[0]), false, false);
+    l_fin = __uint_as_float(sw[0]);
+  }
+  const float inv = 1.0f / l_fin;
   if (qrow < p.Lq) {
     T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 x0, x1;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { x0[i] = o0[4 * g4 + i] * inv; x1[i] = o1[4 * g4 + i] * inv; }
+      for (int i = 0; i < 4; ++i) {
+        x0[i] = (FOLD ? ot0[4 * g4 + i] : o0[4 * g4 + i]) * inv;
+        x1[i] = (FOLD ? ot1[4 * g4 + i] : o1[4 * g4 + i]) * inv;
+      }
       *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
       *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
     }
     if (p.lse != nullptr && hi == 0)
-      p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_run * p.scale + __logf(l_tot);
+      p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_run * p.scale + __logf(l_fin);
   }
 }
 
-template <typename T, int NW>
+template <typename T, int NW, bool FOLD, int ABL = 0>
 hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   AttnKParams p = p0;
   constexpr int QB = NW * 32;
   p.nqb = (p.Lq + QB - 1) / QB;
   const int grid = p.B * p.H * p.nqb;
-  hipLaunchKernelGGL((shared_attn_fwd_kernel<T, NW>), dim3(grid), dim3(NW * 64), 0, s, p);
+  hipLaunchKernelGGL((shared_attn_fwd_kernel<T, NW, FOLD, ABL>), dim3(grid), dim3(NW * 64), 0, s, p);
   return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
+  const bool fold = (p.aa != nullptr);
+  if (nw == 8) return fold ? launch<T, 8, true>(p, s) : launch<T, 8, false>(p, s);
+  return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
 }
 
 }  // namespace
 
-// variant: 0 = auto (8 waves for long query axes, 4 waves when that would leave CUs idle),
-//          1 = force 8 waves, 2 = force 4 waves
+// variant & 15: 0 = auto (two independent 4-wave workgroups per CU: measured faster than one
+//               8-wave workgroup at every layer class), 1 = force 8 waves, 2 = force 4 waves
+// variant >> 4: ablation bits (timing experiments; bf16, 4 waves, no AdaIN only; WRONG results)
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
-  int nw = 8;
-  if (variant == 2) nw = 4;
-  else if (variant == 0) {
-    const long blocks8 = (long)p.B * p.H * ((p.Lq + 255) / 256);
-    if (blocks8 < 256 || p.Lq <= 128) nw = 4;
+  const int abl = variant >> 4;
+  if (abl != 0) {
+    switch (abl & 7) {
+      case 1: return launch<__bf16, 4, false, 1>(p, s);
+      case 2: return launch<__bf16, 4, false, 2>(p, s);
+      case 3: return launch<__bf16, 4, false, 3>(p, s);
+      case 4: return launch<__bf16, 4, false, 4>(p, s);
+      case 5: return launch<__bf16, 4, false, 5>(p, s);
+      case 6: return launch<__bf16, 4, false, 6>(p, s);
+      default: return launch<__bf16, 4, false, 7>(p, s);
+    }
   }
-  if (dtype == 1) return nw == 8 ? launch<__bf16, 8>(p, s) : launch<__bf16, 4>(p, s);
-  return nw == 8 ? launch<_Float16, 8>(p, s) : launch<_Float16, 4>(p, s);
+  const int nw = ((variant & 15) == 1) ? 8 : 4;
+  return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);
 }

@@ -89,7 +89,9 @@ def _epilogue(attn, st: _Prepared, tokens: torch.Tensor) -> torch.Tensor:
         out = out.transpose(-1, -2).reshape(bsz, ch, hh, ww)
     if attn.residual_connection:
         out = out + st.residual
-    return out / attn.rescale_output_factor
+    if attn.rescale_output_factor != 1.0:  # x / 1.0 == x bit-for-bit: skip the launch (always 1.0 in SD-Turbo)
+        out = out / attn.rescale_output_factor
+    return out
 
 
 def _same_16bit(q: torch.Tensor, *others: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:

@@ -1,0 +1,105 @@
+"""Multi-GPU execution of the hot path: independent identities, one process per GPU.
+
+Every identity ``b`` is independent through the whole pipeline - the shared attention never
+mixes batch entries (``ref_keys[b]`` only feeds sample ``b``, attn_processors.py:238-241) - so
+the path shards embarrassingly: a contiguous split of the identities over the ranks, weights
+replicated, NO collective on the data path.  The reference has no
+inference-time distribution at all (its only multi-GPU code is training DDP through accelerate,
+coach.py:52-61); this is the MI355X deployment shape for it.
+
+The only traffic is the optional batch scatter / output gather when one rank owns the inputs.
+Over xGMI (point-to-point, 7 links per GPU) that is issued as one grouped batch of send/recv
+pairs, so every link carries exactly one peer's shard - never a ring.  With ``backend="nccl"``
+these are RCCL ``ncclSend/ncclRecv`` inside one group; with ``gloo`` (CPU tests) plain TCP.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
+    """contiguous split; the first ``total % world`` ranks get one extra identity"""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world: {rank}/{world}")
+    base, extra = divmod(total, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_sizes(total: int, world: int) -> List[int]:
+    return [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)]
+
+
+def _world(group) -> Tuple[int, int]:
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, 0
+    return dist.get_world_size(group), dist.get_rank(group)
+
+
+def scatter_identities(full: Optional[torch.Tensor], total: int, tail_shape: Sequence[int], dtype: torch.dtype,
+                       device: torch.device, src: int = 0, group=None) -> torch.Tensor:
+    """Rank ``src`` holds ``full`` of shape ``(total, *tail_shape)``; every rank returns its
+    contiguous shard.  One grouped batch of point-to-point transfers (one peer per link)."""
+    world, rank = _world(group)
+    lo, hi = shard_range(total, world, rank)
+    if world == 1:
+        return full[lo:hi]
+    ops, keep = [], []
+    if rank == src:
+        if full is None or full.shape[0] != total:
+            raise ValueError("source rank must pass the full batch")
+        for r in range(world):
+            if r == src:
+                continue
+            rlo, rhi = shard_range(total, world, r)
+            if rhi > rlo:
+                piece = full[rlo:rhi].contiguous()
+                keep.append(piece)
+                ops.append(dist.P2POp(dist.isend, piece, r, group))
+        mine = full[lo:hi].clone()
+    else:
+        mine = torch.empty((hi - lo, *tail_shape), dtype=dtype, device=device)
+        if hi > lo:
+            ops.append(dist.P2POp(dist.irecv, mine, src, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return mine
+
+
+def gather_identities(shard: torch.Tensor, total: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+    """Inverse of :func:`scatter_identities`: rank ``dst`` returns ``(total, ...)``, others None."""
+    world, rank = _world(group)
+    if world == 1:
+        return shard
+    ops = []
+    out = None
+    if rank == dst:
+        out = torch.empty((total, *shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        for r in range(world):
+            rlo, rhi = shard_range(total, world, r)
+            if r == dst:
+                out[rlo:rhi].copy_(shard)
+            elif rhi > rlo:
+                ops.append(dist.P2POp(dist.irecv, out[rlo:rhi], r, group))
+    elif shard.shape[0] > 0:
+        ops.append(dist.P2POp(dist.isend, shard.contiguous(), dst, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return out
+
+
+def run_sharded(step_fn, degraded: Optional[torch.Tensor], refs: Optional[torch.Tensor], total: int,
+                img_shape: Sequence[int], n_refs: int, dtype: torch.dtype, device: torch.device, group=None):
+    """scatter -> ``step_fn(degraded_shard, refs_shard)`` on every rank -> gather on rank 0.
+
+    ``degraded`` ``(total, *img_shape)`` and ``refs`` ``(total, n_refs, *img_shape)`` live on
+    rank 0 (others pass ``None``); the batch layout is the caller's (test.py:79-111)."""
+    d = scatter_identities(degraded, total, tuple(img_shape), dtype, device, 0, group)
+    r = scatter_identities(refs, total, (n_refs, *img_shape), dtype, device, 0, group)
+    out = step_fn(d, r)
+    return gather_identities(out, total, 0, group)

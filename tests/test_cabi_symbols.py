@@ -1,0 +1,69 @@
+"""The C-ABI library loads (CPU-only box: no compute calls) and exports every symbol that
+include/instantrestore_hip.h declares; the ctypes mirror agrees with the header."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "instantrestore_hip.h")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ir_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    from instantrestore_amd import _lib
+    names = _declared()
+    assert {"ir_shared_attn_fwd", "ir_adain_stats", "ir_adain_apply", "ir_attn_probs", "ir_token_stats",
+            "ir_zero_invalid_refs", "ir_abi_version", "ir_last_error_string"} <= set(names)
+    lib = _lib.lib()
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+        assert n in _lib.SYMBOLS, f"{n} has no ctypes prototype in instantrestore_amd/_lib.py"
+    assert sorted(_lib.SYMBOLS) == names
+    assert lib.ir_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define IR_ABI_VERSION (\d+)", open(HEADER).read()).group(1))
+    assert b"gfx950" in lib.ir_build_info()
+
+
+def test_struct_mirror_matches_header_field_order():
+    from instantrestore_amd import _lib
+    text = open(HEADER).read()
+    body = re.search(r"typedef struct ir_shared_attn_args \{(.*?)\} ir_shared_attn_args;", text, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split()[-1] if "," not in decl else None
+        if names is None:
+            first, *rest = decl.split(",")
+            fields.append(first.split()[-1].lstrip("*"))
+            fields += [r.strip().lstrip("*") for r in rest]
+        else:
+            fields.append(names.lstrip("*"))
+    assert fields == [f[0] for f in _lib.SharedAttnArgs._fields_]
+    assert C.sizeof(_lib.SharedAttnArgs) == 10 * 4 + 9 * 8 + 20 * 8
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    """validation happens before any launch: callable on the CPU-only box"""
+    from instantrestore_amd import _lib
+    lib = _lib.lib()
+    a = _lib.SharedAttnArgs()
+    assert lib.ir_shared_attn_fwd(None, None) == -1
+    a.struct_size = 7
+    assert lib.ir_shared_attn_fwd(C.byref(a), None) == -1 and b"ABI mismatch" in lib.ir_last_error_string()
+    a.struct_size = C.sizeof(a)
+    a.dtype = 5
+    assert lib.ir_shared_attn_fwd(C.byref(a), None) == -2
+    a.dtype, a.batch, a.heads, a.len_q = 1, 1, 1, 8
+    assert lib.ir_shared_attn_fwd(C.byref(a), None) == -1          # empty K/V sequence
+    assert lib.ir_adain_stats_workspace_bytes(8, 5, 4096, 4, 4096) == 8 * 5 * 5 * 16 * 128 * 4
+    with pytest.raises(_lib.IRError):
+        _lib.check(-1, "demo")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IR_ABI_VERSION 1
+#define IR_ABI_VERSION 2
 #define IR_HEAD_DIM 64
 
 typedef enum ir_status {
@@ -98,7 +98,18 @@ typedef struct ir_shared_attn_args {
   int64_t kr_sb, kr_sn, kr_sl, kr_sh;
   int64_t vr_sb, vr_sn, vr_sl, vr_sh;
   int64_t o_sb, o_sl, o_sh;
+  void* workspace;          /* optional device scratch (see ir_shared_attn_workspace_bytes), or NULL */
+  uint64_t workspace_bytes;
 } ir_shared_attn_args;
+
+/*
+ * Scratch for the remainder split: when the number of (batch, head, query-block) work items is not
+ * a multiple of the resident workgroup slots, the items of the last, partially filled round are
+ * cut into K/V-range pieces whose partial (O, max, sum) results are merged by a second small
+ * kernel, so that round ends early instead of running at full length.  Passing NULL (or a smaller
+ * buffer) only disables (or limits) the split; results are identical up to fp32 rounding.
+ */
+size_t ir_shared_attn_workspace_bytes(void);
 
 int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream);
 

@@ -12,7 +12,7 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libinstantrestore_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 IR_DTYPE_F16, IR_DTYPE_BF16 = 0, 1
 IR_FLAG_INCLUDE_SELF = 1
@@ -30,6 +30,7 @@ class SharedAttnArgs(C.Structure):
         + [(n, i64) for n in ("q_sb", "q_sl", "q_sh", "ks_sb", "ks_sl", "ks_sh", "vs_sb", "vs_sl", "vs_sh",
                               "kr_sb", "kr_sn", "kr_sl", "kr_sh", "vr_sb", "vr_sn", "vr_sl", "vr_sh",
                               "o_sb", "o_sl", "o_sh")]
+        + [("workspace", vp), ("workspace_bytes", C.c_uint64)]
     )
 
 
@@ -39,6 +40,7 @@ SYMBOLS = {
     "ir_build_info": (C.c_char_p, []),
     "ir_last_error_string": (C.c_char_p, []),
     "ir_set_attn_variant": (C.c_int, [C.c_int]),
+    "ir_shared_attn_workspace_bytes": (C.c_size_t, []),
     "ir_shared_attn_fwd": (C.c_int, [C.POINTER(SharedAttnArgs), vp]),
     "ir_time_shared_attn_fwd": (C.c_int, [C.POINTER(SharedAttnArgs), i32, vp, C.POINTER(f32)]),
     "ir_attn_probs": (C.c_int, [C.POINTER(SharedAttnArgs), vp, vp]),

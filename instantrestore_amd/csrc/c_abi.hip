@@ -69,6 +69,9 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->lkv = (inc ? a->len_self : 0) + a->n_refs * a->len_ref;
   p->scale = a->scale;
   p->scale_log2 = a->scale * 1.4426950408889634f;
+  if (a->workspace != nullptr && !aligned16(a->workspace)) return fail(IR_ERR_UNSUPPORTED, "workspace must be 16-byte aligned");
+  p->ws = (float*)a->workspace;
+  p->ws_bytes = a->workspace != nullptr ? (size_t)a->workspace_bytes : 0;
   const int64_t blocks = (int64_t)a->batch * a->heads * ((a->len_q + 127) / 128);
   if (blocks > 0x7fffffffLL) return fail(IR_ERR_UNSUPPORTED, "grid too large");
   return IR_OK;
@@ -85,6 +88,9 @@ const char* ir_build_info(void) { return "instantrestore_hip gfx950 (CDNA4) hipc
 const char* ir_last_error_string(void) { return g_err; }
 
 int ir_set_attn_variant(int variant) { return g_variant.exchange(variant); }
+
+// 8 XCDs x 64 slots pieces of up to 256 rows, 64 fp32 of O + (max, sum) per row
+size_t ir_shared_attn_workspace_bytes(void) { return (size_t)8 * 64 * 256 * 66 * sizeof(float); }
 
 int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream) {
   AttnKParams p;

@@ -34,6 +34,18 @@ struct AttnKParams {
   int lkv;            // include_self*Ls + N*Lr
   float scale;
   float scale_log2;   // scale * log2(e)
+  // remainder split (pipelined kernel): each XCD owns sk_ix consecutive work items; the first
+  // sk_full of them (whole rounds of the XCD's workgroup slots) run their full K/V range, each
+  // of the remaining sk_ix - sk_full is cut into sk_k pieces along the K/V tiles whose partial
+  // (O, m, l) go to ws_o / ws_ml and are merged by the combine kernel.  sk_k <= 1: no split.
+  float* ws;          // caller's workspace (or nullptr: never split)
+  size_t ws_bytes;
+  float* ws_o;        // [piece][QB rows][64] fp32, unnormalised O relative to m
+  float* ws_ml;       // [piece][QB rows][2]  (raw running max, row sum)
+  int sk_items;       // B*H*nqb
+  int sk_ix;          // ceil(sk_items / 8)
+  int sk_full;
+  int sk_k;
 };
 
 struct AdainKParams {
@@ -70,6 +82,8 @@ struct ZeroRefsKParams {
 
 // launchers (defined next to their kernels); dtype: 0 = f16, 1 = bf16. Return hipError_t.
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s);
+hipError_t ir_launch_shared_attn_fwd_pipe(const AttnKParams& p, int dtype, int nw, hipStream_t s);
+hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hipStream_t s);
 hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_token_stats(const AdainKParams& p, int dtype, hipStream_t s);

@@ -409,6 +409,7 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 // variant >> 4: ablation bits (timing experiments; bf16, 4 waves, no AdaIN only; WRONG results)
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
   const int abl = variant >> 4;
+  if (abl != 0 && (variant & 15) == 3) return ir_launch_shared_attn_fwd_pipe_abl(p, abl, s);
   if (abl != 0) {
     switch (abl & 7) {
       case 1: return launch<__bf16, 4, false, 1>(p, s);
@@ -420,6 +421,10 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
       default: return launch<__bf16, 4, false, 7>(p, s);
     }
   }
-  const int nw = ((variant & 15) == 1) ? 8 : 4;
+  const int base = variant & 15;
+  if (base == 0 || base == 3) return ir_launch_shared_attn_fwd_pipe(p, dtype, 4, s);  // default: software-pipelined, 4 waves
+  if (base == 4) return ir_launch_shared_attn_fwd_pipe(p, dtype, 8, s);  // software-pipelined, 8 waves
+  if (base == 5) return ir_launch_shared_attn_fwd_pipe(p, dtype, 5, s);  // pipelined, 4 waves, hoisted LDS reads
+  const int nw = (base == 1) ? 8 : 4;
   return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);
 }

@@ -1,0 +1,585 @@
+// shared_attn_fwd_pipe.hip - software-pipelined variant of the fused extended self-attention
+// forward (gfx950).  Same math, layouts and C-ABI contract as shared_attn_fwd.hip; what changes
+// is the schedule inside a wave.
+//
+// PMC + ablation of the straight-line kernel (profiles/, tools/gpu_ablate.py) showed that its
+// phases - LDS fragment reads, QK^T MFMAs, softmax VALU, PV MFMAs, staging - are serialised per
+// wave (removing any one buys ~20 %, additively) and that two waves per SIMD only overlap
+// statistically.  Here each iteration t issues, in ONE basic block,
+//
+//        S(t+1) = K[t+1] Q^T          (8 MFMA, matrix pipe)
+//        P(t)   = softmax step on S(t) (VALU: v_max3 / v_pk_fma / v_exp / v_cvt_pk)
+//        O     += V[t]^T P(t)^T        (8 MFMA)
+//
+// so the matrix pipe works on tile t+1's scores while the VALU exponentiates tile t's.  K is
+// staged one tile further ahead than V: K ring of 2, V ring of 3 (one prefetch stream, tiles
+// arrive as (K[j], V[j]) pairs two iterations ahead of their PV).
+//
+// VALU diet (D = 64 is VALU-issue bound): row sums as packed v_pk_add_f32 into two 2-wide
+// accumulators; scale-and-subtract as v_pk_fma_f32; AdaIN folded per SEGMENT with a lazily
+// rescaled total that lives in LDS (private slot per thread), so the per-tile rescale touches
+// only the 32 current accumulators and the fold costs nothing per tile.
+#include <type_traits>
+
+#include "ir_common.h"
+#include "ir_kernels.h"
+
+namespace {
+
+constexpr int KVB = IR_KV_TILE;
+constexpr int TILE_BYTES = KVB * 64 * 2;  // 8 KiB
+
+// ABL (timing experiments only, WRONG results): 1 = no barrier, 2 = no LDS staging writes,
+// 4 = no global loads, 8 = no exp/pack VALU, 16 = no LDS fragment reads
+template <typename T, int NW, bool FOLD, int ABL = 0>
+__global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_pipe_kernel(const AttnKParams p) {
+  using Tr = ElemTraits<T>;
+  using v8 = typename Tr::v8;
+  using v4 = typename Tr::v4;
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;
+  constexpr int CH = (KVB * 8) / NT;
+  constexpr int K_OFF = 0;                       // K ring: 2 tiles
+  constexpr int V_OFF = 2 * TILE_BYTES;          // V ring: 3 tiles
+  constexpr int OT_OFF = 5 * TILE_BYTES;         // folded total: 32 floats per thread
+  constexpr int LDS_BYTES = OT_OFF + (FOLD ? NT * 32 * 4 : 0);
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5;
+  const int lq = lane & 31;
+
+  // ---- work decode: XCD x = blockIdx % 8 owns items [x*sk_ix, (x+1)*sk_ix); its first sk_full
+  // slots are whole items, the rest are K/V-range pieces of the remainder items (so the last,
+  // partially filled round of workgroup slots is cut short instead of running at full length) --
+  const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+  int item_local, piece = 0, npiece = 1;
+  if (xslot < p.sk_full) {
+    item_local = xslot;
+  } else {
+    npiece = p.sk_k;
+    const int r = xslot - p.sk_full;
+    item_local = p.sk_full + r / npiece;
+    piece = r - (r / npiece) * npiece;
+  }
+  const int lin = xcd * p.sk_ix + item_local;
+  if (item_local >= p.sk_ix || lin >= p.sk_items) return;  // padding of the last XCD chunk
+  const int tile_begin = (int)(((long)p.ntiles * piece) / npiece);
+  const int tile_end = (int)(((long)p.ntiles * (piece + 1)) / npiece);
+  const int bh = lin / p.nqb;
+  const int qb = lin - bh * p.nqb;
+  const int b = bh / p.H;
+  const int h = bh - b * p.H;
+
+  const int qrow = qb * QB + wid * 32 + lq;
+  const int qrow_c = qrow < p.Lq ? qrow : p.Lq - 1;
+  v8 qf[4];
+  {
+    const T* qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)qrow_c * p.q_sl + (int64_t)h * p.q_sh + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8*)(qp + ks * 16);
+  }
+
+  // ---- staging coordinates -------------------------------------------------------------------
+  const int slot = tid & 7;
+  int srow[CH], koff[CH], voff[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int row = (tid >> 3) + c * (NT / 8);
+    srow[c] = row;
+    koff[c] = row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+    voff[c] = row * 128 + ((slot ^ (((row >> 1) & 1) << 2)) << 4);
+  }
+  int kread[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kread[ks] = lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4);
+  int vread[2];
+  {
+    const int m = lane & 15, g = (lane >> 4) & 1;
+    const int sw = (m >> 3) & 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+      vread[db] = (4 * hi + (m >> 2)) * 128 + ((db ^ sw) << 6) + 32 * g + 8 * (m & 3);
+  }
+  float* const ot_lds = (float*)(smem + OT_OFF) + tid;  // element r at ot_lds[r * NT]
+  if (FOLD) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) ot_lds[r * NT] = 0.f;
+  }
+
+  // ---- prefetch stream (tile pairs j = 0, 1, 2, ...) ---------------------------------------------
+  const int nseg = p.include_self + p.N;
+  __amdgpu_buffer_rsrc_t krs, vrs;
+  int kstep = 0, vstep = 0, sntile = 0;
+  unsigned kvo[CH], vvo[CH];
+  auto seg_setup = [&](int s) {
+    const T* sk;
+    const T* sv;
+    int ksl_b, vsl_b, slen;
+    if (p.include_self && s == 0) {
+      sk = (const T*)p.k_self + (int64_t)b * p.ks_sb + (int64_t)h * p.ks_sh;
+      sv = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
+      ksl_b = (int)p.ks_sl * 2; vsl_b = (int)p.vs_sl * 2; slen = p.Ls; sntile = p.tiles_self;
+    } else {
+      const int n = s - p.include_self;
+      sk = (const T*)p.k_ref + (int64_t)b * p.kr_sb + (int64_t)n * p.kr_sn + (int64_t)h * p.kr_sh;
+      sv = (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)n * p.vr_sn + (int64_t)h * p.vr_sh;
+      ksl_b = (int)p.kr_sl * 2; vsl_b = (int)p.vr_sl * 2; slen = p.Lr; sntile = p.tiles_ref;
+    }
+    krs = __builtin_amdgcn_make_buffer_rsrc((void*)sk, 0, (slen - 1) * ksl_b + 128, 0x00020000);
+    vrs = __builtin_amdgcn_make_buffer_rsrc((void*)sv, 0, (slen - 1) * vsl_b + 128, 0x00020000);
+    kstep = KVB * ksl_b;
+    vstep = KVB * vsl_b;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      kvo[c] = (unsigned)(srow[c] * ksl_b + slot * 16);
+      vvo[c] = (unsigned)(srow[c] * vsl_b + slot * 16);
+    }
+  };
+  u32x4 kreg[CH], vreg[CH];
+  int seg = 0, t0 = 0;
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      kreg[c] = __builtin_amdgcn_raw_buffer_load_b128(krs, kvo[c], 0, 0);
+      vreg[c] = __builtin_amdgcn_raw_buffer_load_b128(vrs, vvo[c], 0, 0);
+      kvo[c] += kstep;
+      vvo[c] += vstep;
+    }
+  };
+  auto stage_write = [&](int kslot, int vslot) {
+    unsigned char* Kb = smem + K_OFF + kslot * TILE_BYTES;
+    unsigned char* Vb = smem + V_OFF + vslot * TILE_BYTES;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      *(u32x4*)(Kb + koff[c]) = kreg[c];
+      *(u32x4*)(Vb + voff[c]) = vreg[c];
+    }
+  };
+  auto advance = [&]() {
+    if (++t0 == sntile) {
+      t0 = 0;
+      if (++seg < nseg) seg_setup(seg);
+    }
+  };
+
+  // ---- state ---------------------------------------------------------------------------------
+  f32x16 o0, o1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+  f32x2 la = {0.f, 0.f}, lb = {0.f, 0.f};  // this lane's partial row sums of the current segment
+  float l_tot = 0.f;                        // FOLD: folded row sum, relative to m_ot
+  float m_ot = -INFINITY;                   // FOLD: the running max the LDS total is scaled to
+  float m_run = -INFINITY;
+  const float c2 = p.scale_log2;
+  const int NTILES = tile_end - tile_begin;  // tiles of THIS piece (all of them when not split)
+
+  // PV/softmax stream position (the QK^T of tile t+1 is issued unmasked; masking happens when a
+  // tile reaches its softmax step, so the MFMAs and the VALU below share one basic block)
+  int seg_b = 0, t0_b = tile_begin;  // (segment, tile within segment) of the first tile
+  if (!(p.include_self && tile_begin < p.tiles_self)) {
+    const int r = tile_begin - p.tiles_self;  // tiles_self == 0 without a self segment
+    seg_b = p.include_self + r / p.tiles_ref;
+    t0_b = r - (r / p.tiles_ref) * p.tiles_ref;
+  }
+  int cseg = seg_b, ct0 = t0_b;
+  const bool first_is_self = (p.include_self && seg_b == 0);
+  int c_ntile = first_is_self ? p.tiles_self : p.tiles_ref;
+  int c_len = first_is_self ? p.Ls : p.Lr;
+
+  constexpr bool HOIST = (ABL & 32) != 0;  // issue the LDS fragment reads a phase early (real variant)
+  auto load_kf = [&](v8 (&kf0)[4], v8 (&kf1)[4], int kslot) {
+    const unsigned char* Kb = smem + K_OFF + kslot * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf0[ks] = (ABL & 16) ? qf[(ks + 1) & 3] : *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks]);
+      kf1[ks] = (ABL & 16) ? qf[(ks + 2) & 3] : *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks]);
+    }
+  };
+  auto qk_mfma = [&](f32x16& s0, f32x16& s1, const v8 (&kf0)[4], const v8 (&kf1)[4]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s0 = Tr::mfma(kf0[ks], qf[ks], s0);
+      s1 = Tr::mfma(kf1[ks], qf[ks], s1);
+    }
+  };
+  auto qk = [&](f32x16& s0, f32x16& s1, int kslot) {
+    v8 kf0[4], kf1[4];
+    load_kf(kf0, kf1, kslot);
+    qk_mfma(s0, s1, kf0, kf1);
+  };
+  auto load_vf = [&](v8 (&vf0)[4], v8 (&vf1)[4], const unsigned char* Vb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // j = 2*kb + ks
+      const int off = (32 * (j >> 1) + 16 * (j & 1)) * 128;
+      vf0[j] = join_tr<v8>(lds_read_tr16(Vb + vread[0] + off), lds_read_tr16(Vb + vread[0] + off + 8 * 128));
+      vf1[j] = join_tr<v8>(lds_read_tr16(Vb + vread[1] + off), lds_read_tr16(Vb + vread[1] + off + 8 * 128));
+    }
+  };
+
+  // Fold the current segment's accumulators into the lazily scaled LDS total:
+  //   total = total * 2^((m_ot - m_run) c) + O_seg o a_seg + rowsum(P_seg) * b_seg
+  // (a = 1, b = 0 for the self segment).  Linear in the keys, so folding a PART of a segment (a
+  // K/V-range piece ending mid-segment) is equally valid.
+  auto fold_segment = [&]() {
+    float lseg = (la[0] + la[1]) + (lb[0] + lb[1]);
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lseg), __float_as_uint(lseg), false, false);
+      lseg = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    const float f = fast_exp2((m_ot - m_run) * c2);  // m_ot = -inf the first time: f = 0
+    l_tot = l_tot * f + lseg;
+    m_ot = m_run;
+    const bool is_ref = !(p.include_self && cseg == 0);
+    const int n = cseg - p.include_self;
+    const int64_t ao = ((int64_t)(b * p.N + (is_ref ? n : 0)) * p.H + h) * 64 + 4 * hi;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 a0 = {1.f, 1.f, 1.f, 1.f}, a1 = a0, b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+      if (is_ref) {
+        a0 = *(const f32x4*)(p.aa + ao + 8 * g4); a1 = *(const f32x4*)(p.aa + ao + 32 + 8 * g4);
+        b0 = *(const f32x4*)(p.ab + ao + 8 * g4); b1 = *(const f32x4*)(p.ab + ao + 32 + 8 * g4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g4 + i;
+        const float t0o = ot_lds[r * NT], t1o = ot_lds[(16 + r) * NT];
+        ot_lds[r * NT] = __builtin_fmaf(o0[r], a0[i], __builtin_fmaf(lseg, b0[i], t0o * f));
+        ot_lds[(16 + r) * NT] = __builtin_fmaf(o1[r], a1[i], __builtin_fmaf(lseg, b1[i], t1o * f));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    la = f32x2{0.f, 0.f};
+    lb = f32x2{0.f, 0.f};
+  };
+
+  // One pipeline step for tile t.  FAST = steady state (tiles t+1 and t+2 exist): no uniform
+  // branches between the QK^T MFMAs of tile t+1 and the exp/PV work of tile t.
+  auto step = [&](auto fast_tag, int t, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1, int vcur) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    const bool has1 = FAST || (t + 1 < NTILES), has2 = FAST || (t + 2 < NTILES);
+    const unsigned char* Vb = smem + V_OFF + vcur * TILE_BYTES;
+
+    // (1) ragged tail of a segment: mask keys past its end (wave-uniform branch, rare)
+    const int valid = c_len - ct0 * KVB;
+    if (valid < KVB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= valid) c0[r] = -INFINITY;
+        if (key + 32 >= valid) c1[r] = -INFINITY;
+      }
+    }
+    v8 kf0[4], kf1[4], vf0[4], vf1[4];
+    if (HOIST) {  // K fragments of tile t+1 fly while the max chain runs
+      if (has1) load_kf(kf0, kf1, (t + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // (2) row max of S(t): two v_max3 chains + one cross-half exchange
+    float mxa = max3(c0[0], c0[1], c0[2]);
+    float mxb = max3(c1[0], c1[1], c1[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) {
+      mxa = max3(mxa, c0[r], c0[r + 1]);
+      mxb = max3(mxb, c1[r], c1[r + 1]);
+    }
+    float mx = max3(mxa, mxb, max3(c0[15], c1[15], c1[15]));
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), mx);
+    }
+    const float m_new = max3(m_run, mx, mx);
+    const float mc = m_new * c2;
+    // (3) rescale only when some row's max moved (exact)
+    if (__any(m_new != m_run)) {
+      const float alpha = fast_exp2(m_run * c2 - mc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      la *= alpha;
+      lb *= alpha;
+      m_run = m_new;
+    }
+    // (4) the overlapped block: prefetch issue, S(t+1) on the matrix pipe, exp/pack on the VALU,
+    //     PV(t) on the matrix pipe
+    if (HOIST) {  // V fragments of tile t fly under the QK^T MFMAs and the exp work
+      load_vf(vf0, vf1, Vb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (has2 && !(ABL & 4)) issue_loads();
+    if (has1) {
+      if (HOIST) qk_mfma(n0, n1, kf0, kf1);
+      else qk(n0, n1, (t + 1) & 1);
+    }
+    const f32x2 cc = {c2, c2};
+    const f32x2 nm = {-mc, -mc};
+    if (!(ABL & 8))
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 t0v = {c0[r], c0[r + 1]};
+      f32x2 t1v = {c1[r], c1[r + 1]};
+      t0v = __builtin_elementwise_fma(t0v, cc, nm);
+      t1v = __builtin_elementwise_fma(t1v, cc, nm);
+      t0v[0] = fast_exp2(t0v[0]); t0v[1] = fast_exp2(t0v[1]);
+      t1v[0] = fast_exp2(t1v[0]); t1v[1] = fast_exp2(t1v[1]);
+      la += t0v;
+      lb += t1v;
+      c0[r] = t0v[0]; c0[r + 1] = t0v[1];
+      c1[r] = t1v[0]; c1[r + 1] = t1v[1];
+    }
+    v8 pk[2][2];
+    pk[0][0] = __builtin_convertvector(__builtin_shufflevector(c0, c0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+    pk[0][1] = __builtin_convertvector(__builtin_shufflevector(c0, c0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+    pk[1][0] = __builtin_convertvector(__builtin_shufflevector(c1, c1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+    pk[1][1] = __builtin_convertvector(__builtin_shufflevector(c1, c1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = (32 * kb + 16 * ks) * 128;
+        if (HOIST) {
+          o0 = Tr::mfma(vf0[2 * kb + ks], pk[kb][ks], o0);
+          o1 = Tr::mfma(vf1[2 * kb + ks], pk[kb][ks], o1);
+        } else if (ABL & 16) {
+          o0 = Tr::mfma(qf[kb + ks], pk[kb][ks], o0);
+          o1 = Tr::mfma(qf[3 - kb - ks], pk[kb][ks], o1);
+        } else {
+          const s16x4 a00 = lds_read_tr16(Vb + vread[0] + off);
+          const s16x4 a01 = lds_read_tr16(Vb + vread[0] + off + 8 * 128);
+          const s16x4 a10 = lds_read_tr16(Vb + vread[1] + off);
+          const s16x4 a11 = lds_read_tr16(Vb + vread[1] + off + 8 * 128);
+          o0 = Tr::mfma(join_tr<v8>(a00, a01), pk[kb][ks], o0);
+          o1 = Tr::mfma(join_tr<v8>(a10, a11), pk[kb][ks], o1);
+        }
+      }
+    }
+    // (5) segment boundary of this stream: fold the AdaIN affine into the LDS total
+    if (++ct0 == c_ntile) {
+      if (FOLD) fold_segment();
+      ct0 = 0;
+      ++cseg;
+      c_ntile = p.tiles_ref;
+      c_len = p.Lr;
+    }
+    // (6) land pair t+2 in LDS
+    if (has2) {
+      if (!(ABL & 2)) stage_write(t & 1, (vcur >= 1) ? vcur - 1 : 2);  // K slot (t+2)&1, V slot (vcur+2)%3
+      else if (!(ABL & 4)) {
+#pragma unroll
+        for (int c = 0; c < CH; ++c) asm volatile("" ::"v"(kreg[c]), "v"(vreg[c]));  // keep the loads alive
+      }
+      advance();
+    }
+    if (!(ABL & 1)) __syncthreads();
+  };
+
+  // ---- prologue: pairs 0 and 1 into LDS, S(0) ---------------------------------------------------
+  seg = seg_b;
+  t0 = t0_b;
+  seg_setup(seg);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) { kvo[c] += (unsigned)(t0 * kstep); vvo[c] += (unsigned)(t0 * vstep); }
+  issue_loads();
+  stage_write(0, 0);
+  advance();
+  if (NTILES > 1) {
+    issue_loads();
+    stage_write(1, 1);
+    advance();
+  }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks]));  // retire the Q loads before the loop
+  __syncthreads();
+
+  f32x16 sa0, sa1, sb0, sb1;
+  qk(sa0, sa1, 0);
+  // S(0) is read by inline-asm v_max3 right away in the first step: pad the MFMA->VALU hazard
+  asm volatile("s_nop 7\n\ts_nop 4" : "+v"(sa0), "+v"(sa1));
+
+  int t = 0, vcur = 0;  // vcur = V ring slot of tile t
+  auto next3 = [](int v) { return v == 2 ? 0 : v + 1; };
+  const std::integral_constant<bool, true> fast{};
+  const std::integral_constant<bool, false> slow{};
+  for (; t + 3 < NTILES; t += 2) {  // steady state: both tiles of the pair have t+2 < NTILES
+    step(fast, t, sa0, sa1, sb0, sb1, vcur);
+    vcur = next3(vcur);
+    step(fast, t + 1, sb0, sb1, sa0, sa1, vcur);
+    vcur = next3(vcur);
+  }
+  for (; t < NTILES; t += 2) {      // tail (and tiny problems): runtime-checked steps
+    step(slow, t, sa0, sa1, sb0, sb1, vcur);
+    vcur = next3(vcur);
+    if (t + 1 < NTILES) {
+      step(slow, t + 1, sb0, sb1, sa0, sa1, vcur);
+      vcur = next3(vcur);
+    }
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  if (FOLD && ct0 != 0) fold_segment();  // a piece that stops inside a segment folds what it has
+  float l_fin;
+  if (FOLD) {
+    l_fin = l_tot;  // everything is folded and m_ot == m_run
+  } else {
+    float ls = (la[0] + la[1]) + (lb[0] + lb[1]);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+    l_fin = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  if (npiece > 1) {
+    // partial result of a K/V-range piece: unnormalised O (fp32), raw max, row sum -> workspace
+    const int64_t prow = ((int64_t)((xcd * (p.sk_ix - p.sk_full) + (item_local - p.sk_full)) * npiece + piece)) * QB + wid * 32 + lq;
+    float* wo = p.ws_o + prow * 64;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 x0, x1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g4 + i;
+        x0[i] = FOLD ? ot_lds[r * NT] : o0[r];
+        x1[i] = FOLD ? ot_lds[(16 + r) * NT] : o1[r];
+      }
+      *(f32x4*)(wo + 8 * g4 + 4 * hi) = x0;
+      *(f32x4*)(wo + 32 + 8 * g4 + 4 * hi) = x1;
+    }
+    if (hi == 0) {
+      p.ws_ml[prow * 2] = m_run;
+      p.ws_ml[prow * 2 + 1] = l_fin;
+    }
+    return;
+  }
+  const float inv = 1.0f / l_fin;
+  if (qrow < p.Lq) {
+    T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 x0, x1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g4 + i;
+        x0[i] = (FOLD ? ot_lds[r * NT] : o0[r]) * inv;
+        x1[i] = (FOLD ? ot_lds[(16 + r) * NT] : o1[r]) * inv;
+      }
+      *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
+      *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
+    }
+    if (p.lse != nullptr && hi == 0)
+      p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_run * p.scale + __logf(l_fin);
+  }
+}
+
+// Merge the K/V-range pieces of the remainder items: one workgroup per remainder item, thread =
+// (row, 32-channel half).  out = sum_j w_j O_j / sum_j w_j l_j with w_j = 2^((m_j - M) c).
+template <typename T, int QB>
+__global__ void __launch_bounds__(QB * 2) shared_attn_combine_kernel(const AttnKParams p) {
+  using v8 = typename ElemTraits<T>::v8;
+  const int xcd = blockIdx.x & 7, ri = blockIdx.x >> 3;  // ri: remainder item index inside the XCD chunk
+  const int rem_x = p.sk_ix - p.sk_full;
+  const int item_local = p.sk_full + ri;
+  const int lin = xcd * p.sk_ix + item_local;
+  if (ri >= rem_x || lin >= p.sk_items) return;
+  const int bh = lin / p.nqb, qb = lin - bh * p.nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+  const int qrow = qb * QB + row;
+  if (qrow >= p.Lq) return;
+  const int64_t base = (int64_t)(xcd * rem_x + ri) * p.sk_k;
+  float M = -INFINITY;
+  for (int j = 0; j < p.sk_k; ++j) M = fmaxf(M, p.ws_ml[((base + j) * QB + row) * 2]);
+  float acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+  float L = 0.f;
+  for (int j = 0; j < p.sk_k; ++j) {
+    const int64_t prow = (base + j) * QB + row;
+    const float w = fast_exp2((p.ws_ml[prow * 2] - M) * p.scale_log2);
+    L += w * p.ws_ml[prow * 2 + 1];
+    const float* wo = p.ws_o + prow * 64 + half * 32;
+#pragma unroll
+    for (int i = 0; i < 32; i += 4) {
+      const f32x4 x = *(const f32x4*)(wo + i);
+      acc[i] += w * x[0]; acc[i + 1] += w * x[1]; acc[i + 2] += w * x[2]; acc[i + 3] += w * x[3];
+    }
+  }
+  const float inv = 1.0f / L;
+  T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh + half * 32;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    f32x8 x;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = acc[i + e] * inv;
+    *(v8*)(op + i) = __builtin_convertvector(x, v8);
+  }
+  if (p.lse != nullptr && half == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = M * p.scale + __logf(L);
+}
+
+// Work plan: items = B*H*ceil(Lq/QB); every XCD owns ix = ceil(items/8) consecutive items and
+// has `slots_x` concurrently resident workgroups (CUs/8 * workgroups per CU).  Whole rounds run
+// full K/V ranges; the remainder items are cut into k pieces so the last round ends early.
+template <typename T, int NW, bool FOLD, int ABL = 0>
+hipError_t launch(const AttnKParams& p0, hipStream_t s) {
+  AttnKParams p = p0;
+  constexpr int QB = NW * 32;
+  p.nqb = (p.Lq + QB - 1) / QB;
+  p.sk_items = p.B * p.H * p.nqb;
+  p.sk_ix = (p.sk_items + 7) / 8;
+  const int slots_x = 32 * (NW == 8 ? 1 : 2);
+  int full = (p.sk_ix / slots_x) * slots_x;
+  int rem = p.sk_ix - full;
+  int k = 1;
+  if (p.ws != nullptr && rem > 0) {
+    k = slots_x / rem;
+    const int kmax = p.ntiles / 8;  // keep pieces at least 8 tiles long
+    if (k > kmax) k = kmax;
+    const size_t piece_bytes = (size_t)QB * 66 * sizeof(float);
+    const size_t cap = p.ws_bytes / piece_bytes;  // pieces the caller's workspace can hold
+    if ((size_t)8 * rem * k > cap) k = (int)(cap / ((size_t)8 * rem));
+    if (k < 1) k = 1;
+  }
+  if (k <= 1) { full = p.sk_ix; rem = 0; k = 1; }
+  p.sk_full = full;
+  p.sk_k = k;
+  p.ws_o = p.ws;
+  p.ws_ml = p.ws + (size_t)8 * rem * k * QB * 64;
+  const int grid = 8 * (full + rem * k);
+  hipLaunchKernelGGL((shared_attn_fwd_pipe_kernel<T, NW, FOLD, ABL>), dim3(grid), dim3(NW * 64), 0, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || k <= 1) return e;
+  hipLaunchKernelGGL((shared_attn_combine_kernel<T, QB>), dim3(8 * rem), dim3(QB * 2), 0, s, p);
+  return hipGetLastError();
+}
+
+template <typename T>
+hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
+  const bool fold = (p.aa != nullptr);
+  if (nw == 8) return fold ? launch<T, 8, true>(p, s) : launch<T, 8, false>(p, s);
+  if (nw == 5) return fold ? launch<T, 4, true, 32>(p, s) : launch<T, 4, false, 32>(p, s);  // hoisted LDS reads
+  return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
+}
+
+}  // namespace
+
+hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hipStream_t s) {
+  switch (abl) {
+    case 1: return launch<__bf16, 4, false, 1>(p, s);
+    case 2: return launch<__bf16, 4, false, 2>(p, s);
+    case 3: return launch<__bf16, 4, false, 3>(p, s);
+    case 4: return launch<__bf16, 4, false, 4>(p, s);
+    case 6: return launch<__bf16, 4, false, 6>(p, s);
+    case 7: return launch<__bf16, 4, false, 7>(p, s);
+    case 8: return launch<__bf16, 4, false, 8>(p, s);
+    case 15: return launch<__bf16, 4, false, 15>(p, s);
+    case 16: return launch<__bf16, 4, false, 16>(p, s);
+    case 23: return launch<__bf16, 4, false, 23>(p, s);
+    case 31: return launch<__bf16, 4, false, 31>(p, s);
+    default: return launch<__bf16, 4, false, 0>(p, s);
+  }
+}
+
+hipError_t ir_launch_shared_attn_fwd_pipe(const AttnKParams& p, int dtype, int nw, hipStream_t s) {
+  return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);
+}

@@ -73,7 +73,7 @@ def _ref(t: torch.Tensor, heads: int, name: str) -> torch.Tensor:
     return t
 
 
-def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse):
+def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split=True):
     a = _lib.SharedAttnArgs()
     a.struct_size = C.sizeof(_lib.SharedAttnArgs)
     a.dtype = _dtype_code(q)
@@ -100,7 +100,24 @@ def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adai
         a.o_sb, a.o_sl, a.o_sh = out.stride(0), out.stride(1), HEAD_DIM
     if lse is not None:
         a.lse = lse.data_ptr()
+    if out is not None and split:  # scratch for the remainder split (ir_shared_attn_workspace_bytes)
+        ws = _workspace(q.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        a._keepalive = ws
     return a
+
+
+_WS = {}
+
+
+def _workspace(device: torch.device) -> torch.Tensor:
+    """one scratch buffer per (device, stream): launches on one stream are ordered, so reuse is safe"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.empty(_lib.lib().ir_shared_attn_workspace_bytes() // 4, dtype=torch.float32, device=device)
+        _WS[key] = ws
+    return ws
 
 
 def _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain):
@@ -133,7 +150,7 @@ def _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain):
 
 def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
                      include_self: bool = True, adain: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                     return_lse: bool = False):
+                     return_lse: bool = False, split: bool = True):
     """Fused extended self-attention (``ir_shared_attn_fwd``).
 
     Returns ``out`` (B, Lq, H*64) in q's dtype [and ``lse`` (B, H, Lq) fp32].  ``adain`` is the
@@ -143,17 +160,17 @@ def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, s
     q, k_self, v_self, ref_k, ref_v = _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain)
     out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=q.dtype, device=q.device)
     lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if return_lse else None
-    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse)
+    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split)
     _lib.check(_lib.lib().ir_shared_attn_fwd(C.byref(args), _stream()), "ir_shared_attn_fwd")
     return (out, lse) if return_lse else out
 
 
 def time_shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
-                          include_self: bool = True, adain=None, iters: int = 10) -> float:
+                          include_self: bool = True, adain=None, iters: int = 10, split: bool = True) -> float:
     """Average ms per launch measured with HIP events on the launch stream (``bench.py``)."""
     q, k_self, v_self, ref_k, ref_v = _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain)
     out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=q.dtype, device=q.device)
-    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, None)
+    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, None, split)
     ms = C.c_float(0.0)
     _lib.check(_lib.lib().ir_time_shared_attn_fwd(C.byref(args), int(iters), _stream(), C.byref(ms)),
                "ir_time_shared_attn_fwd")

@@ -64,7 +64,7 @@ CORE_CASES = [
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("case", CORE_CASES, ids=[f"B{c[0]}H{c[1]}L{c[2]}N{c[3]}Lr{c[4]}s{int(c[5])}a{int(c[6])}p{int(c[7])}" for c in CORE_CASES])
-@pytest.mark.parametrize("variant", [1, 2], ids=["w8", "w4"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5], ids=["w8", "w4", "pipe4", "pipe8", "pipe4h"])
 def test_core_parity(ops, case, dtype, variant):
     B, H, Lq, N, Lr, inc, ad, peaky = case
     gen = torch.Generator().manual_seed(1234 + Lq + 7 * N)
@@ -319,7 +319,7 @@ def test_errors_are_loud(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
-@pytest.mark.parametrize("variant", [1, 2], ids=["w8", "w4"])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5], ids=["w8", "w4", "pipe4", "pipe8", "pipe4h"])
 @pytest.mark.parametrize("shape", [(64, 0, 0, True), (256, 2, 128, True), (100, 3, 72, False), (512, 4, 512, True)])
 def test_onehot_attention_exposes_layout_and_hazard_bugs(ops, dtype, variant, shape):
     """every query attends to exactly one key (logit margin ~40): the output row must BE that
@@ -335,3 +335,26 @@ def test_onehot_attention_exposes_layout_and_hazard_bugs(ops, dtype, variant, sh
         assert mod.onehot_case(dtype, L, N, Lr, inc, variant)
     finally:
         ops.set_attn_variant(0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 5, 1024, 4, True, True), (3, 2, 512, 2, False, True), (1, 3, 2048, 0, True, False)])
+def test_remainder_split_equals_unsplit(ops, dtype, shape):
+    """work items that do not fill the last round of workgroup slots are cut into K/V-range pieces
+    and merged by the combine kernel: same result (fp32 re-association only) as the unsplit run,
+    LSE included, with and without the AdaIN fold, also when a piece ends inside a segment."""
+    B, H, L, N, inc, ad = shape
+    gen = torch.Generator().manual_seed(31 + L)
+    C = H * 64
+    q, k, v = (_rand((B, L, C), dtype, gen).cuda() for _ in range(3))
+    rk = rv = aff = None
+    if N:
+        rk, rv = _rand((B, N, L, C), dtype, gen).cuda(), _rand((B, N, L, C), dtype, gen, 1.2, 0.5).cuda()
+        aff = ops.adain_stats(v, rv, heads=H) if ad else None
+    kw = dict(heads=H, scale=0.125, include_self=inc, adain=aff, return_lse=True)
+    o1, l1 = ops.shared_attention(q, k, v, rk, rv, split=True, **kw)
+    o0, l0 = ops.shared_attention(q, k, v, rk, rv, split=False, **kw)
+    assert (o1.float() - o0.float()).abs().max().item() <= TOL[dtype]
+    assert (l1 - l0).abs().max().item() <= 1e-4
+    ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.125, ad and N > 0, inc)
+    _check(o1, ref, dtype, "split")

@@ -119,7 +119,8 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
     tf = flops / (ms * 1e-3) / 1e12
     return {
         "bound": "mfma",
-        "kernel": "shared_attn_fwd_kernel (L=%d, Lkv=%d, H=%d, B=%d)" % (L, lkv, H, B),
+        "kernel": "shared_attn_fwd_pipe_kernel<%s,4 waves,%s> (L=%d, Lkv=%d, H=%d, B=%d)" % (
+            {torch.bfloat16: "bf16", torch.float16: "f16"}[dtype], "AdaIN fold" if use_adain else "no fold", L, lkv, H, B),
         "achieved": round(tf, 2),
         "peak": MFMA_PEAK_TFLOPS_16BIT,
         "unit": "TFLOP/s",
@@ -127,8 +128,26 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         "ms_per_launch": round(ms, 4),
         "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
         "algorithmic_mb_per_launch": round(attn_bytes(B, L, lkv, C) / 1e6, 2),
-        "traffic": None,  # HBM bytes from rocprofv3 --pmc: see profiles/ (filled per round in DESIGN.md)
+        # HBM bytes per launch from a separate rocprofv3 --pmc pass of this kernel at this shape
+        # (tools/pmc_attn.sh -> profiles/r1_pmc_shared_attn_pipe.txt); FETCH_SIZE doubled per the
+        # gfx950 correction of MI355X_MICROARCH.md.  null if the profile is not for this shape.
+        "traffic": _pmc_traffic_mb() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
+        "traffic_unit": "MB",
     }
+
+
+def _pmc_traffic_mb():
+    import ast
+    path = os.path.join(REPO, "profiles", "r1_pmc_shared_attn_pipe.txt")
+    try:
+        vals = {}
+        for line in open(path):
+            i, j = line.find("{"), line.rfind("}")
+            if i >= 0 and j > i:
+                vals.update(ast.literal_eval(line[i:j + 1]))
+        return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / 1e6, 1)
+    except Exception:
+        return None
 
 
 def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=25.0):

@@ -71,4 +71,35 @@ static __device__ __forceinline__ float max3(float a, float b, float c) {
   return r;
 }
 
+// LDS-DMA: 16 bytes per lane straight from a buffer resource into LDS at (wave-uniform base +
+// lane*16).  Kept in a __device__ helper: the host pass must not see the address-space cast.
+static __device__ __forceinline__ void buffer_load_lds16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_base,
+                                                         unsigned voffset) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (IR_LDS void*)lds_base, 16, voffset, 0, 0, 0);
+}
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// Raw buffer descriptor words (base, stride 0, num_records, flags) for hand-issued buffer ops.
+static __device__ __forceinline__ i32x4 make_rsrc_words(const void* base, unsigned num_records) {
+  const unsigned long long a = (unsigned long long)base;
+  i32x4 r;
+  r[0] = (int)(unsigned)a;
+  r[1] = (int)((unsigned)(a >> 32) & 0xffffu);
+  r[2] = (int)num_records;
+  r[3] = 0x00020000;
+  return r;
+}
+
+// LDS-DMA issued from inline asm: invisible to hipcc's waitcnt bookkeeping, so the transfer stays
+// in flight across LDS reads until OUR s_waitcnt vmcnt(0) (placed before the step's barrier).
+// M0 (the LDS destination base) is written in the same statement that consumes it.
+static __device__ __forceinline__ void buffer_load_lds16_async(i32x4 rsrc, unsigned char* lds_base, unsigned voffset) {
+  const unsigned lds_addr = (unsigned)(unsigned long long)(IR_LDS unsigned char*)lds_base;
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :
+               : "s"(lds_addr), "v"(voffset), "s"(rsrc)
+               : "memory");
+}
+
 static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

@@ -32,7 +32,7 @@ constexpr int TILE_BYTES = KVB * 64 * 2;  // 8 KiB
 // ABL (timing experiments only, WRONG results): 1 = no barrier, 2 = no LDS staging writes,
 // 4 = no global loads, 8 = no exp/pack VALU, 16 = no LDS fragment reads
 template <typename T, int NW, bool FOLD, int ABL = 0>
-__global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_pipe_kernel(const AttnKParams p) {
+__global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_pipe_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
   using v4 = typename Tr::v4;
@@ -111,6 +111,9 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_pipe_kernel(const 
   }
 
   // ---- prefetch stream (tile pairs j = 0, 1, 2, ...) ---------------------------------------------
+  constexpr bool DMA_FLAG = (ABL & (64 | 128 | 256)) != 0;
+  constexpr bool DMA_ASM = (ABL & (128 | 256)) != 0;  // DMA issued from inline asm, waited for by hand
+  i32x4 krw = {0, 0, 0, 0}, vrw = {0, 0, 0, 0};
   const int nseg = p.include_self + p.N;
   __amdgpu_buffer_rsrc_t krs, vrs;
   int kstep = 0, vstep = 0, sntile = 0;
@@ -131,15 +134,38 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_pipe_kernel(const 
     }
     krs = __builtin_amdgcn_make_buffer_rsrc((void*)sk, 0, (slen - 1) * ksl_b + 128, 0x00020000);
     vrs = __builtin_amdgcn_make_buffer_rsrc((void*)sv, 0, (slen - 1) * vsl_b + 128, 0x00020000);
+    if (DMA_ASM) {
+      krw = make_rsrc_words(sk, (unsigned)((slen - 1) * ksl_b + 128));
+      vrw = make_rsrc_words(sv, (unsigned)((slen - 1) * vsl_b + 128));
+    }
     kstep = KVB * ksl_b;
     vstep = KVB * vsl_b;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      kvo[c] = (unsigned)(srow[c] * ksl_b + slot * 16);
-      vvo[c] = (unsigned)(srow[c] * vsl_b + slot * 16);
+      // register staging: thread fetches logical slot `slot` and writes it to the swizzled LDS
+      // position; LDS-DMA: the LDS position is lane-linear (physical slot = tid & 7), so the thread
+      // fetches the logical slot that belongs there (the XOR swizzles are involutions)
+      const int ks_ = DMA_FLAG ? (slot ^ ((srow[c] >> 1) & 7)) : slot;
+      const int vs_ = DMA_FLAG ? (slot ^ (((srow[c] >> 1) & 1) << 2)) : slot;
+      kvo[c] = (unsigned)(srow[c] * ksl_b + ks_ * 16);
+      vvo[c] = (unsigned)(srow[c] * vsl_b + vs_ * 16);
     }
   };
   u32x4 kreg[CH], vreg[CH];
+  auto issue_dma = [&](int kslot, int vslot) {  // tile pair straight into its ring slots
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      if (DMA_ASM) {
+        buffer_load_lds16_async(krw, smem + K_OFF + kslot * TILE_BYTES + (c * NW + wid) * 1024, kvo[c]);
+        buffer_load_lds16_async(vrw, smem + V_OFF + vslot * TILE_BYTES + (c * NW + wid) * 1024, vvo[c]);
+      } else {
+        buffer_load_lds16(krs, smem + K_OFF + kslot * TILE_BYTES + (c * NW + wid) * 1024, kvo[c]);
+        buffer_load_lds16(vrs, smem + V_OFF + vslot * TILE_BYTES + (c * NW + wid) * 1024, vvo[c]);
+      }
+      kvo[c] += kstep;
+      vvo[c] += vstep;
+    }
+  };
   int seg = 0, t0 = 0;
   auto issue_loads = [&]() {
 #pragma unroll
@@ -190,6 +216,8 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_pipe_kernel(const 
   int c_ntile = first_is_self ? p.tiles_self : p.tiles_ref;
   int c_len = first_is_self ? p.Ls : p.Lr;
 
+  constexpr bool NOPIPE = (ABL & 256) != 0;  // no S double buffer: fewer VGPRs, three waves per SIMD (implies asm DMA)
+  constexpr bool DMA = (ABL & (64 | 128 | 256)) != 0;    // global->LDS staging by LDS-DMA (buffer_load ... lds), no registers (real variant)
   constexpr bool HOIST = (ABL & 32) != 0;  // issue the LDS fragment reads a phase early (real variant)
   auto load_kf = [&](v8 (&kf0)[4], v8 (&kf1)[4], int kslot) {
     const unsigned char* Kb = smem + K_OFF + kslot * TILE_BYTES;
@@ -266,6 +294,14 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_pipe_kernel(const 
     const bool has1 = FAST || (t + 1 < NTILES), has2 = FAST || (t + 2 < NTILES);
     const unsigned char* Vb = smem + V_OFF + vcur * TILE_BYTES;
 
+    if (NOPIPE) {  // straight schedule: prefetch pair t+1, S(t) now
+      if (has1) {
+        issue_dma((t + 1) & 1, vcur == 2 ? 0 : vcur + 1);
+        advance();
+      }
+      qk(c0, c1, t & 1);
+      asm volatile("s_nop 7\n\ts_nop 4" : "+v"(c0), "+v"(c1));  // MFMA -> asm v_max3 hazard pad
+    }
     // (1) ragged tail of a segment: mask keys past its end (wave-uniform branch, rare)
     const int valid = c_len - ct0 * KVB;
     if (valid < KVB) {
@@ -311,8 +347,11 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_pipe_kernel(const 
       load_vf(vf0, vf1, Vb);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (has2 && !(ABL & 4)) issue_loads();
-    if (has1) {
+    if (!NOPIPE && has2 && !(ABL & 4)) {
+      if (DMA) issue_dma(t & 1, (vcur >= 1) ? vcur - 1 : 2);  // K slot (t+2)&1, V slot (vcur+2)%3: both free since the last barrier
+      else issue_loads();
+    }
+    if (!NOPIPE && has1) {
       if (HOIST) qk_mfma(n0, n1, kf0, kf1);
       else qk(n0, n1, (t + 1) & 1);
     }
@@ -367,14 +406,16 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_pipe_kernel(const 
       c_len = p.Lr;
     }
     // (6) land pair t+2 in LDS
-    if (has2) {
-      if (!(ABL & 2)) stage_write(t & 1, (vcur >= 1) ? vcur - 1 : 2);  // K slot (t+2)&1, V slot (vcur+2)%3
+    if (!NOPIPE && has2) {
+      if (DMA) {}
+      else if (!(ABL & 2)) stage_write(t & 1, (vcur >= 1) ? vcur - 1 : 2);  // K slot (t+2)&1, V slot (vcur+2)%3
       else if (!(ABL & 4)) {
 #pragma unroll
         for (int c = 0; c < CH; ++c) asm volatile("" ::"v"(kreg[c]), "v"(vreg[c]));  // keep the loads alive
       }
       advance();
     }
+    if (DMA_ASM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // our DMA of pair t+2 has landed
     if (!(ABL & 1)) __syncthreads();
   };
 
@@ -384,27 +425,45 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_pipe_kernel(const 
   seg_setup(seg);
 #pragma unroll
   for (int c = 0; c < CH; ++c) { kvo[c] += (unsigned)(t0 * kstep); vvo[c] += (unsigned)(t0 * vstep); }
-  issue_loads();
-  stage_write(0, 0);
-  advance();
-  if (NTILES > 1) {
-    issue_loads();
-    stage_write(1, 1);
+  if (DMA) {
+    issue_dma(0, 0);
     advance();
+    if (!NOPIPE && NTILES > 1) {
+      issue_dma(1, 1);
+      advance();
+    }
+    if (DMA_ASM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    issue_loads();
+    stage_write(0, 0);
+    advance();
+    if (NTILES > 1) {
+      issue_loads();
+      stage_write(1, 1);
+      advance();
+    }
   }
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks]));  // retire the Q loads before the loop
   __syncthreads();
 
   f32x16 sa0, sa1, sb0, sb1;
-  qk(sa0, sa1, 0);
-  // S(0) is read by inline-asm v_max3 right away in the first step: pad the MFMA->VALU hazard
-  asm volatile("s_nop 7\n\ts_nop 4" : "+v"(sa0), "+v"(sa1));
+  if (!NOPIPE) {
+    qk(sa0, sa1, 0);
+    // S(0) is read by inline-asm v_max3 right away in the first step: pad the MFMA->VALU hazard
+    asm volatile("s_nop 7\n\ts_nop 4" : "+v"(sa0), "+v"(sa1));
+  }
 
   int t = 0, vcur = 0;  // vcur = V ring slot of tile t
   auto next3 = [](int v) { return v == 2 ? 0 : v + 1; };
   const std::integral_constant<bool, true> fast{};
   const std::integral_constant<bool, false> slow{};
+  if (NOPIPE) {
+    for (; t < NTILES; ++t) {
+      step(slow, t, sa0, sa1, sa0, sa1, vcur);
+      vcur = next3(vcur);
+    }
+  }
   for (; t + 3 < NTILES; t += 2) {  // steady state: both tiles of the pair have t+2 < NTILES
     step(fast, t, sa0, sa1, sb0, sb1, vcur);
     vcur = next3(vcur);
@@ -527,7 +586,7 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.nqb = (p.Lq + QB - 1) / QB;
   p.sk_items = p.B * p.H * p.nqb;
   p.sk_ix = (p.sk_items + 7) / 8;
-  const int slots_x = 32 * (NW == 8 ? 1 : 2);
+  const int slots_x = 32 * (NW == 8 ? 1 : ((ABL & 256) ? 3 : 2));
   int full = (p.sk_ix / slots_x) * slots_x;
   int rem = p.sk_ix - full;
   int k = 1;
@@ -558,6 +617,9 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   const bool fold = (p.aa != nullptr);
   if (nw == 8) return fold ? launch<T, 8, true>(p, s) : launch<T, 8, false>(p, s);
   if (nw == 5) return fold ? launch<T, 4, true, 32>(p, s) : launch<T, 4, false, 32>(p, s);  // hoisted LDS reads
+  if (nw == 6) return fold ? launch<T, 4, true, 64>(p, s) : launch<T, 4, false, 64>(p, s);  // LDS-DMA staging
+  if (nw == 7) return fold ? launch<T, 4, true, 128>(p, s) : launch<T, 4, false, 128>(p, s);  // LDS-DMA from asm
+  if (nw == 9) return fold ? launch<T, 4, true, 256>(p, s) : launch<T, 4, false, 256>(p, s);  // straight schedule, 3 waves/SIMD
   return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
 }
 

@@ -94,6 +94,43 @@ def _epilogue(attn, st: _Prepared, tokens: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _project_qkv(attn, st: _Prepared):
+    """``to_q`` / ``to_k`` / ``to_v`` of the reference (attn_processors.py:222-230).
+
+    Self-attention with three plain bias-free ``nn.Linear`` projections of equal shape runs them
+    as ONE GEMM against a cached concatenation of the three weights (SURVEY.md section 8f rank
+    4): the fused attention kernel reads q / k / v as strided views of that single ``(B, L, 3C)``
+    result, so nothing is copied.  Same values as three separate calls (each output column is
+    the same dot product).  Anything else - cross attention, peft/LoRA-wrapped or biased
+    projections, training - takes the three module calls exactly like the reference."""
+    src = _kv_source(attn, st)
+    tq, tk, tv = attn.to_q, attn.to_k, attn.to_v
+    fusable = (
+        st.encoder is None
+        and type(tq) is nn.Linear and type(tk) is nn.Linear and type(tv) is nn.Linear
+        and tq.bias is None and tk.bias is None and tv.bias is None
+        and tq.weight.shape == tk.weight.shape == tv.weight.shape
+        and not torch.is_grad_enabled()
+    )
+    if not fusable:
+        return tq(st.hidden), tk(src), tv(src)
+    if st.hidden.is_cuda and torch.is_autocast_enabled("cuda"):
+        dtype = torch.get_autocast_dtype("cuda")
+    else:
+        dtype = tq.weight.dtype
+    key = (tq.weight.data_ptr(), tk.weight.data_ptr(), tv.weight.data_ptr(),
+           tq.weight._version, tk.weight._version, tv.weight._version, dtype, tq.weight.device)
+    cache = attn.__dict__.get("_ir_qkv_cache")  # plain attribute: never part of the state dict
+    if cache is None or cache[0] != key:
+        w = torch.cat([tq.weight.detach(), tk.weight.detach(), tv.weight.detach()], dim=0).to(dtype)
+        cache = (key, w)
+        attn.__dict__["_ir_qkv_cache"] = cache
+    x = st.hidden if st.hidden.dtype == dtype else st.hidden.to(dtype)
+    qkv = torch.nn.functional.linear(x, cache[1])
+    c = tq.weight.shape[0]
+    return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+
+
 def _same_16bit(q: torch.Tensor, *others: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:
     """Under autocast the projections emit fp16/bf16; captured reference K/V have that dtype
     too.  Anything else on this path is a caller error worth hearing about."""
@@ -123,10 +160,8 @@ class AttnProcessor(nn.Module):
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
-        query = attn.to_q(st.hidden)
         self.is_self_attn = encoder_hidden_states is None
-        src = _kv_source(attn, st)
-        key, value = attn.to_k(src), attn.to_v(src)
+        query, key, value = _project_qkv(attn, st)
         self.keys, self.values = key, value  # consumed in place by the shared layers: no copies
         _same_16bit(query, key, value)
         tokens = _ops.shared_attention(query, key, value, heads=attn.heads, scale=attn.scale, include_self=True)
@@ -189,9 +224,7 @@ class SharedAttnProcessor(nn.Module):
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                 ref_keys=None, ref_values=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
-        query = attn.to_q(st.hidden)
-        src = _kv_source(attn, st)
-        key, value = attn.to_k(src), attn.to_v(src)
+        query, key, value = _project_qkv(attn, st)
 
         ref_k = ref_v = None
         include_self = True

@@ -218,7 +218,8 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
 
   constexpr bool NOPIPE = (ABL & 256) != 0;  // no S double buffer: fewer VGPRs, three waves per SIMD (implies asm DMA)
   constexpr bool DMA = (ABL & (64 | 128 | 256)) != 0;    // global->LDS staging by LDS-DMA (buffer_load ... lds), no registers (real variant)
-  constexpr bool HOIST = (ABL & 32) != 0;  // issue the LDS fragment reads a phase early (real variant)
+  constexpr bool HOIST = (ABL & (32 | 512)) != 0;  // issue the K fragment reads a phase early (real variant)
+  constexpr bool HOIST_V = (ABL & 32) != 0;        // ... and the V fragment reads too
   auto load_kf = [&](v8 (&kf0)[4], v8 (&kf1)[4], int kslot) {
     const unsigned char* Kb = smem + K_OFF + kslot * TILE_BYTES;
 #pragma unroll
@@ -343,7 +344,7 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
     }
     // (4) the overlapped block: prefetch issue, S(t+1) on the matrix pipe, exp/pack on the VALU,
     //     PV(t) on the matrix pipe
-    if (HOIST) {  // V fragments of tile t fly under the QK^T MFMAs and the exp work
+    if (HOIST_V) {  // V fragments of tile t fly under the QK^T MFMAs and the exp work
       load_vf(vf0, vf1, Vb);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -381,7 +382,7 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int off = (32 * kb + 16 * ks) * 128;
-        if (HOIST) {
+        if (HOIST_V) {
           o0 = Tr::mfma(vf0[2 * kb + ks], pk[kb][ks], o0);
           o1 = Tr::mfma(vf1[2 * kb + ks], pk[kb][ks], o1);
         } else if (ABL & 16) {
@@ -619,6 +620,7 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   if (nw == 5) return fold ? launch<T, 4, true, 32>(p, s) : launch<T, 4, false, 32>(p, s);  // hoisted LDS reads
   if (nw == 6) return fold ? launch<T, 4, true, 64>(p, s) : launch<T, 4, false, 64>(p, s);  // LDS-DMA staging
   if (nw == 7) return fold ? launch<T, 4, true, 128>(p, s) : launch<T, 4, false, 128>(p, s);  // LDS-DMA from asm
+  if (nw == 10) return fold ? launch<T, 4, true, 128 | 512>(p, s) : launch<T, 4, false, 128 | 512>(p, s);  // asm DMA + K fragments hoisted
   if (nw == 9) return fold ? launch<T, 4, true, 256>(p, s) : launch<T, 4, false, 256>(p, s);  // straight schedule, 3 waves/SIMD
   return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
 }

@@ -180,6 +180,18 @@ int ir_zero_invalid_refs(int32_t batch, int32_t heads, int32_t n_refs, int32_t l
                          void* k, int64_t k_sb, int64_t k_sn, int64_t k_sl, int64_t k_sh,
                          void* v, int64_t v_sb, int64_t v_sn, int64_t v_sl, int64_t v_sh, void* stream);
 
+/*
+ * ir_tensor2im_u8 - the caller's output path on the device.
+ *
+ * Replaces tensor2im(var, unnorm=True) (face_replace/training/utils/vis_utils.py:14-23, called at
+ * face_replace/inference/test.py:139): x*0.5+0.5 in the tensor's dtype, clamp [0,1], *255 in that
+ * dtype, truncation to uint8, CHW -> HWC.  Bit-identical bytes; only H*W*C bytes cross PCIe.
+ *   x (B, C, H, W) strides x_sb, x_sc, x_sh, x_sw (elements); dtype 0 = fp16, 1 = bf16, 2 = fp32
+ *   out_u8 (B, H, W, C) contiguous uint8
+ */
+int ir_tensor2im_u8(int32_t dtype, int32_t batch, int32_t channels, int32_t height, int32_t width, const void* x,
+                    int64_t x_sb, int64_t x_sc, int64_t x_sh, int64_t x_sw, void* out_u8, void* stream);
+
 /* library identity / diagnostics */
 int ir_abi_version(void);                  /* == IR_ABI_VERSION */
 const char* ir_build_info(void);           /* "gfx950 hipcc ... <date>" */

@@ -50,6 +50,7 @@ SYMBOLS = {
     "ir_token_stats": (C.c_int, [i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp, vp, C.c_size_t, vp]),
     "ir_adain_apply": (C.c_int, [i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp,
                                  vp, i64, i64, i64, i64, vp]),
+    "ir_tensor2im_u8": (C.c_int, [i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp]),
     "ir_zero_invalid_refs": (C.c_int, [i32, i32, i32, i32, vp, vp, i64, i64, i64, i64,
                                        vp, i64, i64, i64, i64, vp]),
 }

@@ -235,3 +235,47 @@ hipError_t ir_launch_zero_refs(const ZeroRefsKParams& p, hipStream_t s) {
   hipLaunchKernelGGL(zero_refs_kernel, dim3((unsigned)bx, p.N, p.B), dim3(256), 0, s, p);
   return hipGetLastError();
 }
+
+// ---- tensor2im: (B,3,H,W) in [-1,1] -> uint8 (B,H,W,3), the output path of the caller -------------
+// face_replace/training/utils/vis_utils.py:14-23 (tensor2im(var, unnorm=True), called at
+// inference/test.py:139): var*0.5 + 0.5 IN THE TENSOR'S DTYPE, clamp to [0,1], *255 in that dtype,
+// truncation to uint8, CHW -> HWC.  Done on the device so only H*W*3 bytes cross PCIe.  Every
+// intermediate is rounded to T exactly where the reference rounds, so the bytes are bit-identical.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) tensor2im_kernel(const T* __restrict__ x, unsigned char* __restrict__ out,
+                                                        int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                                                        int B, int C, int H, int W) {
+  const int64_t n = (int64_t)B * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int w = (int)(i % W);
+    const int64_t t = i / W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    const T* px = x + b * sb + h * sh + w * sw;
+    unsigned char* po = out + i * C;
+    for (int c = 0; c < C; ++c) {
+      T v = px[c * sc];
+      v = (T)((float)v * 0.5f);          // var *= 0.5   (exact in binary floating point)
+      v = (T)((float)v + 0.5f);          // var += 0.5   (one rounding to T)
+      float f = (float)v;
+      f = f < 0.f ? 0.f : (f > 1.f ? 1.f : f);
+      v = (T)(f * 255.0f);               // var *= 255   (one rounding to T)
+      po[c] = (unsigned char)(int)(float)v;  // astype('uint8'): truncation
+    }
+  }
+}
+}  // namespace
+
+hipError_t ir_launch_tensor2im(const void* x, void* out, int dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                               int B, int C, int H, int W, hipStream_t s) {
+  const int64_t n = (int64_t)B * H * W;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  const dim3 g((unsigned)blocks), t(256);
+  if (dtype == 0) hipLaunchKernelGGL((tensor2im_kernel<_Float16>), g, t, 0, s, (const _Float16*)x, (unsigned char*)out, sb, sc, sh, sw, B, C, H, W);
+  else if (dtype == 1) hipLaunchKernelGGL((tensor2im_kernel<__bf16>), g, t, 0, s, (const __bf16*)x, (unsigned char*)out, sb, sc, sh, sw, B, C, H, W);
+  else hipLaunchKernelGGL((tensor2im_kernel<float>), g, t, 0, s, (const float*)x, (unsigned char*)out, sb, sc, sh, sw, B, C, H, W);
+  return hipGetLastError();
+}

@@ -236,4 +236,15 @@ int ir_zero_invalid_refs(int32_t batch, int32_t heads, int32_t n_refs, int32_t l
   return IR_OK;
 }
 
+int ir_tensor2im_u8(int32_t dtype, int32_t batch, int32_t channels, int32_t height, int32_t width, const void* x,
+                    int64_t x_sb, int64_t x_sc, int64_t x_sh, int64_t x_sw, void* out_u8, void* stream) {
+  if (dtype < 0 || dtype > 2) return fail(IR_ERR_UNSUPPORTED, "dtype %d (0 f16, 1 bf16, 2 f32)", dtype);
+  if (batch <= 0 || channels <= 0 || height <= 0 || width <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (!x || !out_u8) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  const hipError_t e = ir_launch_tensor2im(x, out_u8, dtype, x_sb, x_sc, x_sh, x_sw, batch, channels, height, width,
+                                           (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "tensor2im launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
 }  // extern "C"

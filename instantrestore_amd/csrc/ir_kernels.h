@@ -89,3 +89,5 @@ hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s
 hipError_t ir_launch_token_stats(const AdainKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_adain_apply(const AdainApplyKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_zero_refs(const ZeroRefsKParams& p, hipStream_t s);
+hipError_t ir_launch_tensor2im(const void* x, void* out, int dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
+                               int B, int C, int H, int W, hipStream_t s);

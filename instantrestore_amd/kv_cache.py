@@ -1,0 +1,69 @@
+"""Per-identity cache of harvested reference K/V.
+
+The reference recomputes the K/V of the reference faces for every restored frame
+(``Pix2Pix_Turbo.forward`` -> ``get_conditioning_keys_values``, pix2pix_turbo.py:297-298): N of
+the N+1 UNet forwards, N of the N+1 VAE encodes and an unused VAE decode (:277-279) per frame,
+although the references of one identity never change.  This cache keeps, per identity, the nine
+``(1, N, L, C)`` key tensors and nine value tensors produced by
+:func:`instantrestore_amd.kv_harvest.get_conditioning_keys_values`; a batch is assembled by
+concatenation along the identity axis (one copy of the cached tensors per batch, instead of N UNet
+forwards per identity).  Behaviour-preserving for inference callers: the K/V handed to the main
+UNet are the same tensors the reference would have recomputed (up to the reference's own RNG:
+``randn_like`` noise at t=1, pix2pix_turbo.py:248 - caching freezes one draw).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Callable, Hashable, List, Sequence, Tuple
+
+import torch
+
+KV = Tuple[List[torch.Tensor], List[torch.Tensor]]
+
+
+class ReferenceKVCache:
+    def __init__(self, max_identities: int = 64):
+        if max_identities < 1:
+            raise ValueError("max_identities must be >= 1")
+        self.max_identities = max_identities
+        self._store: "OrderedDict[Hashable, KV]" = OrderedDict()
+        self.hits = 0
+        self.misses = 0
+
+    def __len__(self) -> int:
+        return len(self._store)
+
+    def __contains__(self, identity: Hashable) -> bool:
+        return identity in self._store
+
+    def get_or_compute(self, identity: Hashable, compute: Callable[[], KV]) -> KV:
+        """``compute()`` must return ``(keys, values)`` for ONE identity: lists of ``(1, N, L, C)``."""
+        if identity in self._store:
+            self._store.move_to_end(identity)
+            self.hits += 1
+            return self._store[identity]
+        self.misses += 1
+        keys, values = compute()
+        if len(keys) != len(values) or any(k.shape[0] != 1 or k.shape != v.shape for k, v in zip(keys, values)):
+            raise ValueError("compute() must return matching lists of (1, N, L, C) tensors")
+        entry = ([k.detach() for k in keys], [v.detach() for v in values])
+        self._store[identity] = entry
+        while len(self._store) > self.max_identities:
+            self._store.popitem(last=False)
+        return entry
+
+    def assemble(self, identities: Sequence[Hashable]) -> KV:
+        """``(B, N, L, C)`` lists for a batch of cached identities (raises KeyError on a miss)."""
+        entries = [self._store[i] for i in identities]
+        for i in identities:
+            self._store.move_to_end(i)
+        n_layers = len(entries[0][0])
+        keys = [torch.cat([e[0][l] for e in entries], dim=0) for l in range(n_layers)]
+        values = [torch.cat([e[1][l] for e in entries], dim=0) for l in range(n_layers)]
+        return keys, values
+
+    def invalidate(self, identity: Hashable = None) -> None:
+        if identity is None:
+            self._store.clear()
+        else:
+            self._store.pop(identity, None)

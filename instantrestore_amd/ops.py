@@ -265,6 +265,26 @@ def zero_invalid_refs(k: torch.Tensor, v: torch.Tensor, valid_indices: torch.Ten
     _lib.check(rc, "ir_zero_invalid_refs")
 
 
+def tensor2im_u8(x: torch.Tensor) -> torch.Tensor:
+    """(B, 3, H, W) or (3, H, W) in [-1, 1] -> uint8 (B, H, W, 3) / (H, W, 3) on the device, with the
+    exact rounding sequence of the reference's ``tensor2im(var, unnorm=True)`` (vis_utils.py:14-23)."""
+    _need_gpu(x)
+    squeeze = x.dim() == 3
+    if squeeze:
+        x = x.unsqueeze(0)
+    if x.dim() != 4:
+        raise ValueError("expected (B, C, H, W) or (C, H, W)")
+    code = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}.get(x.dtype)
+    if code is None:
+        raise TypeError(f"tensor2im_u8: unsupported dtype {x.dtype}")
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, H, W, Cc), dtype=torch.uint8, device=x.device)
+    rc = _lib.lib().ir_tensor2im_u8(code, B, Cc, H, W, x.data_ptr(), x.stride(0), x.stride(1), x.stride(2),
+                                    x.stride(3), out.data_ptr(), _stream())
+    _lib.check(rc, "ir_tensor2im_u8")
+    return out[0] if squeeze else out
+
+
 def set_attn_variant(variant: int) -> int:
     """tuning hook for benchmarks/tests (0 = auto, 1 = 8-wave, 2 = 4-wave workgroups)"""
     return _lib.lib().ir_set_attn_variant(int(variant))

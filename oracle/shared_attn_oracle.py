@@ -208,3 +208,17 @@ def shared_attn_processor_port(hidden, wq, wk, wv, wo, bo, ref_k, ref_v, heads,
     core = shared_attention_port(q, k, v, ref_k, ref_v, heads, (q.shape[-1] // heads) ** -0.5,
                                  use_adain, train_input)
     return F.linear(core, wo, bo)
+
+
+def tensor2im_np(var: np.ndarray) -> np.ndarray:
+    """face_replace/training/utils/vis_utils.py:14-23 with unnorm=True, restated on a numpy array
+    of the tensor's own dtype (float16 / float32; bf16 callers pass float32 values and round with
+    ``round_fn``): (3,H,W) -> uint8 (H,W,3).  Every step rounds to the array dtype like torch does."""
+    v = var.copy()
+    v *= np.asarray(0.5, dtype=v.dtype)
+    v += np.asarray(0.5, dtype=v.dtype)
+    v = np.transpose(v, (1, 2, 0)).copy()
+    v[v < 0] = 0
+    v[v > 1] = 1
+    v *= np.asarray(255, dtype=v.dtype)
+    return v.astype("uint8")

@@ -358,3 +358,27 @@ def test_remainder_split_equals_unsplit(ops, dtype, shape):
     assert (l1 - l0).abs().max().item() <= 1e-4
     ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.125, ad and N > 0, inc)
     _check(o1, ref, dtype, "split")
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16], ids=["f16", "f32", "bf16"])
+def test_tensor2im_bytes_are_identical(ops, dtype):
+    """integer output: bit-exact against the restated tensor2im (vis_utils.py:14-23), including the
+    clamp edges and values that land within one ulp of an integer"""
+    gen = torch.Generator().manual_seed(11)
+    x = (torch.rand(2, 3, 64, 48, generator=gen) * 2.4 - 1.2).to(dtype)
+    x[0, :, 0, :8] = torch.tensor([-1.0, 1.0, 0.0, -0.0, 0.99609375, -0.99609375, 1.5, -1.5]).to(dtype)
+    got = ops.tensor2im_u8(x.cuda()).cpu().numpy()
+    for b in range(2):
+        if dtype == torch.bfloat16:
+            # numpy has no bf16: run the reference sequence in torch on CPU (same rounding per step)
+            v = x[b].clone()
+            v *= 0.5; v += 0.5
+            v = v.permute(1, 2, 0).float().numpy().copy()
+            v[v < 0] = 0; v[v > 1] = 1
+            want = (torch.from_numpy(v).to(torch.bfloat16) * 255).float().numpy().astype("uint8")
+        else:
+            want = O.tensor2im_np(x[b].numpy())
+        assert np.array_equal(got[b], want), f"{(got[b] != want).sum()} differing bytes"
+    # non-contiguous (channels-last view) input is handled through the strides
+    xc = x.cuda().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    assert np.array_equal(ops.tensor2im_u8(xc).cpu().numpy(), got)

@@ -404,10 +404,14 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 
 }  // namespace
 
-// variant & 15: 0 = auto (two independent 4-wave workgroups per CU: measured faster than one
-//               8-wave workgroup at every layer class), 1 = force 8 waves, 2 = force 4 waves
-// variant >> 4: ablation bits (timing experiments; bf16, 4 waves, no AdaIN only; WRONG results)
+// variant & 15 selects the kernel (tuning hook; 0 = default):
+//   0/7 software-pipelined, 4 waves, asm-issued LDS-DMA staging (shared_attn_fwd_pipe.hip)
+//   1/2 this file's straight-line kernel with 8 / 4 waves     3/4 pipelined, register staging, 4 / 8 waves
+//   5 pipelined + hoisted K/V fragment reads   6 pipelined + builtin LDS-DMA   9 straight schedule, 3 waves/SIMD
+//   10 asm DMA + hoisted K fragments
+// variant >> 4: ablation bits - only in -DIR_ABLATIONS builds (timing experiments, WRONG results)
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
+#ifdef IR_ABLATIONS
   const int abl = variant >> 4;
   if (abl != 0 && (variant & 15) == 3) return ir_launch_shared_attn_fwd_pipe_abl(p, abl, s);
   if (abl != 0) {
@@ -421,6 +425,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
       default: return launch<__bf16, 4, false, 7>(p, s);
     }
   }
+#endif
   const int base = variant & 15;
   if (base == 0) return ir_launch_shared_attn_fwd_pipe(p, dtype, 7, s);  // default: software-pipelined, 4 waves, asm-issued LDS-DMA staging
   if (base == 3) return ir_launch_shared_attn_fwd_pipe(p, dtype, 4, s);  // software-pipelined, 4 waves, register staging

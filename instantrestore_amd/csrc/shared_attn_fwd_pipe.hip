@@ -627,7 +627,13 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 
 }  // namespace
 
+// Ablation builds (timing experiments, WRONG results) exist only with -DIR_ABLATIONS
+// (`build.sh -DIR_ABLATIONS`, used by tools/gpu_ablate.py); the shipped library has none.
 hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hipStream_t s) {
+#ifndef IR_ABLATIONS
+  (void)abl;
+  return launch<__bf16, 4, false, 0>(p, s);
+#else
   switch (abl) {
     case 1: return launch<__bf16, 4, false, 1>(p, s);
     case 2: return launch<__bf16, 4, false, 2>(p, s);
@@ -642,6 +648,7 @@ hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hip
     case 31: return launch<__bf16, 4, false, 31>(p, s);
     default: return launch<__bf16, 4, false, 0>(p, s);
   }
+#endif
 }
 
 hipError_t ir_launch_shared_attn_fwd_pipe(const AttnKParams& p, int dtype, int nw, hipStream_t s) {

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Within-process A/B of kernel ablations (interleaved rounds, min and median reported).
+Needs an ablation build of the library: `instantrestore_amd/csrc/build.sh -DIR_ABLATIONS`.
 ABL bits: 1 = no staging/barrier, 2 = no softmax max/exp, 4 = no LDS fragment reads."""
 import sys, os, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

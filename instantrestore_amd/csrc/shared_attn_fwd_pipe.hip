@@ -201,6 +201,9 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
   float m_ot = -INFINITY;                   // FOLD: the running max the LDS total is scaled to
   float m_run = -INFINITY;
   const float c2 = p.scale_log2;
+  if (ABL & 1024) {  // static priority for every other workgroup slot (experiment)
+    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(1);
+  }
   const int NTILES = tile_end - tile_begin;  // tiles of THIS piece (all of them when not split)
 
   // PV/softmax stream position (the QK^T of tile t+1 is issued unmasked; masking happens when a
@@ -342,6 +345,7 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
       lb *= alpha;
       m_run = m_new;
     }
+    if (ABL & 2048) __builtin_amdgcn_s_setprio(1);  // matrix-heavy phase wins arbitration (experiment)
     // (4) the overlapped block: prefetch issue, S(t+1) on the matrix pipe, exp/pack on the VALU,
     //     PV(t) on the matrix pipe
     if (HOIST_V) {  // V fragments of tile t fly under the QK^T MFMAs and the exp work
@@ -416,6 +420,7 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
       }
       advance();
     }
+    if (ABL & 2048) __builtin_amdgcn_s_setprio(0);
     if (DMA_ASM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // our DMA of pair t+2 has landed
     if (!(ABL & 1)) __syncthreads();
   };
@@ -621,6 +626,8 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   if (nw == 6) return fold ? launch<T, 4, true, 64>(p, s) : launch<T, 4, false, 64>(p, s);  // LDS-DMA staging
   if (nw == 7) return fold ? launch<T, 4, true, 128>(p, s) : launch<T, 4, false, 128>(p, s);  // LDS-DMA from asm
   if (nw == 10) return fold ? launch<T, 4, true, 128 | 512>(p, s) : launch<T, 4, false, 128 | 512>(p, s);  // asm DMA + K fragments hoisted
+  if (nw == 11) return fold ? launch<T, 4, true, 128 | 1024>(p, s) : launch<T, 4, false, 128 | 1024>(p, s);  // + static setprio
+  if (nw == 12) return fold ? launch<T, 4, true, 128 | 2048>(p, s) : launch<T, 4, false, 128 | 2048>(p, s);  // + phase setprio
   if (nw == 9) return fold ? launch<T, 4, true, 256>(p, s) : launch<T, 4, false, 256>(p, s);  // straight schedule, 3 waves/SIMD
   return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
 }

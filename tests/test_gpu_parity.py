@@ -382,3 +382,27 @@ def test_tensor2im_bytes_are_identical(ops, dtype):
     # non-contiguous (channels-last view) input is handled through the strides
     xc = x.cuda().permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
     assert np.array_equal(ops.tensor2im_u8(xc).cpu().numpy(), got)
+
+
+def test_randomised_shape_sweep(ops):
+    """40 random small problems (ragged lengths, odd head counts, 0..9 references, both flags, both
+    dtypes) through the default kernel against the float64 oracle."""
+    rng = np.random.default_rng(2024)
+    gen = torch.Generator().manual_seed(2024)
+    for case in range(40):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        Lq = int(rng.integers(1, 200))
+        N = int(rng.integers(0, 10))
+        Lr = int(rng.integers(2, 150)) if N else 0
+        inc = bool(rng.integers(0, 2)) or N == 0
+        ad = bool(rng.integers(0, 2)) and N > 0 and Lq > 1
+        dtype = [torch.float16, torch.bfloat16][case % 2]
+        C = H * 64
+        q, k, v = (_rand((B, Lq, C), dtype, gen, 1.3) for _ in range(3))
+        rk = _rand((B, N, Lr, C), dtype, gen, 1.3) if N else None
+        rv = _rand((B, N, Lr, C), dtype, gen, 0.9, 0.4) if N else None
+        ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.125, ad, inc)
+        c = lambda t: None if t is None else t.cuda()
+        aff = ops.adain_stats(c(v), c(rv), heads=H) if ad else None
+        out = ops.shared_attention(c(q), c(k), c(v), c(rk), c(rv), heads=H, scale=0.125, include_self=inc, adain=aff)
+        _check(out, ref, dtype, f"sweep case {case}: B{B} H{H} Lq{Lq} N{N} Lr{Lr} inc{inc} ad{ad}")

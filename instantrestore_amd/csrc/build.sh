@@ -5,7 +5,7 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${HERE}/../libinstantrestore_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=(shared_attn_fwd.hip shared_attn_fwd_pipe.hip attn_probs.hip adain.hip c_abi.hip)
+SRCS=(shared_attn_fwd.hip shared_attn_fwd_pipe.hip shared_attn_fwd_pp.hip attn_probs.hip adain.hip c_abi.hip)
 cd "${HERE}"
 OBJS=()
 pids=()

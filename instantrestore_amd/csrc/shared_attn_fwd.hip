@@ -435,6 +435,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   if (base == 9) return ir_launch_shared_attn_fwd_pipe(p, dtype, 9, s);  // straight schedule + asm DMA, 3 waves/SIMD
   if (base == 10) return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);  // asm DMA + K fragments hoisted
   if (base == 11 || base == 12) return ir_launch_shared_attn_fwd_pipe(p, dtype, base, s);  // s_setprio experiments
+  if (base == 8) return ir_launch_shared_attn_fwd_pp(p, dtype, s);  // ping-pong wave groups (shared_attn_fwd_pp.hip)
   if (base == 5) return ir_launch_shared_attn_fwd_pipe(p, dtype, 5, s);  // pipelined, 4 waves, hoisted LDS reads
   const int nw = (base == 1) ? 8 : 4;
   return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);

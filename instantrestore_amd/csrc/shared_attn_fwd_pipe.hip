@@ -658,6 +658,18 @@ hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hip
 #endif
 }
 
+// combine launcher shared with the ping-pong kernel (p must carry the final sk_* / ws_* fields)
+hipError_t ir_launch_shared_attn_combine(const AttnKParams& p, int dtype, int qb, int rem, hipStream_t s) {
+  if (qb == 256) {
+    if (dtype == 1) hipLaunchKernelGGL((shared_attn_combine_kernel<__bf16, 256>), dim3(8 * rem), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((shared_attn_combine_kernel<_Float16, 256>), dim3(8 * rem), dim3(512), 0, s, p);
+  } else {
+    if (dtype == 1) hipLaunchKernelGGL((shared_attn_combine_kernel<__bf16, 128>), dim3(8 * rem), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((shared_attn_combine_kernel<_Float16, 128>), dim3(8 * rem), dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
 hipError_t ir_launch_shared_attn_fwd_pipe(const AttnKParams& p, int dtype, int nw, hipStream_t s) {
   return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);
 }

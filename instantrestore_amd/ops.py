@@ -13,6 +13,7 @@ Layouts are the reference's own, consumed IN PLACE (no head-split copies, no ``c
 from __future__ import annotations
 
 import ctypes as C
+import functools
 from typing import Optional, Tuple
 
 import torch
@@ -37,6 +38,25 @@ def _dtype_code(t: torch.Tensor) -> int:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _on_tensor_device(fn):
+    """HIP launches go to the calling thread's CURRENT device: make that the device of the tensors
+    (so a caller holding cuda:1 tensors while cuda:0 is current gets the right device and stream)."""
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = None
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                dev = a.device
+                break
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+
+    return wrapper
 
 
 def _need_gpu(*ts: Optional[torch.Tensor]) -> torch.device:
@@ -148,6 +168,7 @@ def _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain):
     return q, k_self, v_self, ref_k, ref_v
 
 
+@_on_tensor_device
 def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
                      include_self: bool = True, adain: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                      return_lse: bool = False, split: bool = True):
@@ -165,6 +186,7 @@ def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, s
     return (out, lse) if return_lse else out
 
 
+@_on_tensor_device
 def time_shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
                           include_self: bool = True, adain=None, iters: int = 10, split: bool = True) -> float:
     """Average ms per launch measured with HIP events on the launch stream (``bench.py``)."""
@@ -177,6 +199,7 @@ def time_shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: i
     return float(ms.value)
 
 
+@_on_tensor_device
 def attn_probs(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True) -> torch.Tensor:
     """Materialise ``attention_probs`` (B, H, Lq, Lkv) from the LSE of the fused forward
     (``ir_attn_probs``; the ``save_self_attentions`` dump path, attn_processors.py:258-261)."""
@@ -193,6 +216,7 @@ def attn_probs(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self:
     return probs
 
 
+@_on_tensor_device
 def adain_stats(v_self: torch.Tensor, ref_v: torch.Tensor, *, heads: int, eps: float = ADAIN_EPS):
     """AdaIN as a per-(b, n, head, channel) affine ``x*a + b`` (``ir_adain_stats``).
 
@@ -217,6 +241,7 @@ def adain_stats(v_self: torch.Tensor, ref_v: torch.Tensor, *, heads: int, eps: f
     return a, b
 
 
+@_on_tensor_device
 def token_stats(x: torch.Tensor, *, heads: int):
     """mean and unbiased std over the token axis of x (B, M, L, H*64) -> two fp32 (B, M, H, 64)
     tensors (``ir_token_stats``)."""
@@ -235,6 +260,7 @@ def token_stats(x: torch.Tensor, *, heads: int):
     return mean, std
 
 
+@_on_tensor_device
 def adain_apply(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, *, heads: int) -> torch.Tensor:
     """``y = x*a + b`` over (B, N, L, H*64) (``ir_adain_apply``; op-level parity, ``adain()``)."""
     _need_gpu(x, a, b)
@@ -249,6 +275,7 @@ def adain_apply(x: torch.Tensor, a: torch.Tensor, b: torch.Tensor, *, heads: int
     return y
 
 
+@_on_tensor_device
 def zero_invalid_refs(k: torch.Tensor, v: torch.Tensor, valid_indices: torch.Tensor, *, heads: int) -> None:
     """In place: zero K and V of references ``n >= valid_indices[b]`` (``ir_zero_invalid_refs``;
     pix2pix_turbo.py:269-273 - zeroed, not masked)."""
@@ -265,6 +292,7 @@ def zero_invalid_refs(k: torch.Tensor, v: torch.Tensor, valid_indices: torch.Ten
     _lib.check(rc, "ir_zero_invalid_refs")
 
 
+@_on_tensor_device
 def tensor2im_u8(x: torch.Tensor) -> torch.Tensor:
     """(B, 3, H, W) or (3, H, W) in [-1, 1] -> uint8 (B, H, W, 3) / (H, W, 3) on the device, with the
     exact rounding sequence of the reference's ``tensor2im(var, unnorm=True)`` (vis_utils.py:14-23)."""

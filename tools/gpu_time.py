@@ -39,3 +39,20 @@ for (L, C, H) in layer_classes(px):
         row.append(f"v{var}: {ms:8.4f} ms {attn_flops(B * N, L, L, C) / ms / 1e9:7.1f} TF/s")
     print(f"L={L:5d} H={H:2d} plain self-attn x{B*N} | " + " | ".join(row), flush=True)
 ops.set_attn_variant(0)
+
+# AdaIN statistics (HBM-streaming kernel): achieved GB/s against the one-pass byte count
+print("--- adain_stats (one pass over V_self and the N reference V) ---")
+for (L, C, H) in layer_classes(px):
+    v = torch.randn(B, L, C, device="cuda").to(dtype)
+    rv = torch.randn(B, N, L, C, device="cuda").to(dtype)
+    for _ in range(3):
+        ops.adain_stats(v, rv, heads=H)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.adain_stats(v, rv, heads=H)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    nbytes = 2.0 * B * C * (L + N * L)
+    print(f"L={L:5d} C={C:4d}: {ms*1e3:7.1f} us  {nbytes/1e6:7.1f} MB  {nbytes/ms/1e6:7.1f} GB/s  ({nbytes/ms/1e6/8000*100:4.1f}% of 8 TB/s)")

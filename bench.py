@@ -131,12 +131,12 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         # HBM bytes per launch from a separate rocprofv3 --pmc pass of this kernel at this shape
         # (tools/pmc_attn.sh -> profiles/r1_pmc_shared_attn_pipe.txt); FETCH_SIZE doubled per the
         # gfx950 correction of MI355X_MICROARCH.md.  null if the profile is not for this shape.
-        "traffic": _pmc_traffic_mb() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
-        "traffic_unit": "MB",
+        "traffic": _pmc_traffic_bytes() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
+        "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_shared_attn_pipe.txt)",
     }
 
 
-def _pmc_traffic_mb():
+def _pmc_traffic_bytes():
     import ast
     path = os.path.join(REPO, "profiles", "r1_pmc_shared_attn_pipe.txt")
     try:
@@ -145,7 +145,7 @@ def _pmc_traffic_mb():
             i, j = line.find("{"), line.rfind("}")
             if i >= 0 and j > i:
                 vals.update(ast.literal_eval(line[i:j + 1]))
-        return round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / 1e6, 1)
+        return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
     except Exception:
         return None
 

@@ -11,7 +11,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libinstantrestore_hip.so")
+# IR_LIB_PATH: load an alternative build of the same ABI (compiler-flag A/B experiments)
+LIB_PATH = os.environ.get("IR_LIB_PATH") or os.path.join(_HERE, "libinstantrestore_hip.so")
 ABI_VERSION = 2
 
 IR_DTYPE_F16, IR_DTYPE_BF16 = 0, 1

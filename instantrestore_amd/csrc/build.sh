@@ -3,15 +3,16 @@
 # hipcc cross-compiles without a GPU. Usage: build.sh [extra hipcc flags]
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="${HERE}/../libinstantrestore_hip.so"
+OUT="${IR_OUT:-${HERE}/../libinstantrestore_hip.so}"
+BUILD_DIR="${IR_BUILD_DIR:-build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 SRCS=(shared_attn_fwd.hip shared_attn_fwd_pipe.hip shared_attn_fwd_pp.hip attn_probs.hip adain.hip c_abi.hip)
 cd "${HERE}"
 OBJS=()
 pids=()
-mkdir -p build
+mkdir -p "${BUILD_DIR}"
 for s in "${SRCS[@]}"; do
-  o="build/${s%.hip}.o"
+  o="${BUILD_DIR}/${s%.hip}.o"
   OBJS+=("$o")
   "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$s" -o "$o" &
   pids+=($!)

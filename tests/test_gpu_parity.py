@@ -406,3 +406,37 @@ def test_randomised_shape_sweep(ops):
         aff = ops.adain_stats(c(v), c(rv), heads=H) if ad else None
         out = ops.shared_attention(c(q), c(k), c(v), c(rk), c(rv), heads=H, scale=0.125, include_self=inc, adain=aff)
         _check(out, ref, dtype, f"sweep case {case}: B{B} H{H} Lq{Lq} N{N} Lr{Lr} inc{inc} ad{ad}")
+
+
+def test_hip_graph_capture_and_replay(ops):
+    """the library allocates nothing and never synchronises: a whole processor call (projections,
+    AdaIN statistics, fused attention with remainder split, out projection) can be captured in a
+    hipGraph and replayed on new inputs."""
+    from face_replace.models.attn_processors import SharedAttnProcessor
+    from instantrestore_amd.attention import Attention
+    torch.manual_seed(3)
+    B, H, L, N = 2, 2, 192, 3
+    C = H * 64
+    attn = Attention(query_dim=C, heads=H, dim_head=64,
+                     processor=SharedAttnProcessor(self_attn_idx=0, use_adain=True, train_input=True)).cuda().to(torch.bfloat16)
+    x = torch.randn(B, L, C, device="cuda", dtype=torch.bfloat16)
+    rk = [torch.randn(B, N, L, C, device="cuda", dtype=torch.bfloat16)]
+    rv = [torch.randn(B, N, L, C, device="cuda", dtype=torch.bfloat16)]
+    with torch.no_grad():
+        for _ in range(2):  # warm up allocator / hipBLASLt outside the capture
+            attn(x, ref_keys=rk, ref_values=rv)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            attn(x, ref_keys=rk, ref_values=rv)  # workspace for this stream is created here, before capture
+            with torch.cuda.graph(g, stream=stream):
+                y = attn(x, ref_keys=rk, ref_values=rv)
+        torch.cuda.current_stream().wait_stream(stream)
+        x.copy_(torch.randn(B, L, C, device="cuda", dtype=torch.bfloat16))
+        rv[0].mul_(0.5)
+        g.replay()
+        torch.cuda.synchronize()
+        want = attn(x, ref_keys=rk, ref_values=rv)
+    assert torch.equal(y, want)

@@ -407,8 +407,9 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 // variant & 15 selects the kernel (tuning hook; 0 = default):
 //   0/7 software-pipelined, 4 waves, asm-issued LDS-DMA staging (shared_attn_fwd_pipe.hip)
 //   1/2 this file's straight-line kernel with 8 / 4 waves     3/4 pipelined, register staging, 4 / 8 waves
-//   5 pipelined + hoisted K/V fragment reads   6 pipelined + builtin LDS-DMA   9 straight schedule, 3 waves/SIMD
-//   10 asm DMA + hoisted K fragments
+//   6 pipelined + builtin LDS-DMA   8 ping-pong wave groups (shared_attn_fwd_pp.hip)
+//   9 straight schedule + asm DMA at 3 waves/SIMD
+// (tried and removed, see DESIGN.md 4.1: hoisted fragment reads, s_setprio, single-statement asm VALU)
 // variant >> 4: ablation bits - only in -DIR_ABLATIONS builds (timing experiments, WRONG results)
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
 #ifdef IR_ABLATIONS
@@ -433,10 +434,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   if (base == 6) return ir_launch_shared_attn_fwd_pipe(p, dtype, 6, s);  // pipelined, 4 waves, LDS-DMA staging
   if (base == 7) return ir_launch_shared_attn_fwd_pipe(p, dtype, 7, s);  // same, DMA issued from asm
   if (base == 9) return ir_launch_shared_attn_fwd_pipe(p, dtype, 9, s);  // straight schedule + asm DMA, 3 waves/SIMD
-  if (base == 10) return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);  // asm DMA + K fragments hoisted
-  if (base == 11 || base == 12) return ir_launch_shared_attn_fwd_pipe(p, dtype, base, s);  // s_setprio experiments
   if (base == 8) return ir_launch_shared_attn_fwd_pp(p, dtype, s);  // ping-pong wave groups (shared_attn_fwd_pp.hip)
-  if (base == 5) return ir_launch_shared_attn_fwd_pipe(p, dtype, 5, s);  // pipelined, 4 waves, hoisted LDS reads
   const int nw = (base == 1) ? 8 : 4;
   return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);
 }

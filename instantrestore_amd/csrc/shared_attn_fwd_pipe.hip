@@ -32,7 +32,7 @@ constexpr int TILE_BYTES = KVB * 64 * 2;  // 8 KiB
 // ABL (timing experiments only, WRONG results): 1 = no barrier, 2 = no LDS staging writes,
 // 4 = no global loads, 8 = no exp/pack VALU, 16 = no LDS fragment reads
 template <typename T, int NW, bool FOLD, int ABL = 0>
-__global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_pipe_kernel(const AttnKParams p) {
+__global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) shared_attn_fwd_pipe_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
   using v4 = typename Tr::v4;
@@ -201,9 +201,6 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
   float m_ot = -INFINITY;                   // FOLD: the running max the LDS total is scaled to
   float m_run = -INFINITY;
   const float c2 = p.scale_log2;
-  if (ABL & 1024) {  // static priority for every other workgroup slot (experiment)
-    if ((blockIdx.x >> 3) & 1) __builtin_amdgcn_s_setprio(1);
-  }
   const int NTILES = tile_end - tile_begin;  // tiles of THIS piece (all of them when not split)
 
   // PV/softmax stream position (the QK^T of tile t+1 is issued unmasked; masking happens when a
@@ -221,8 +218,6 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
 
   constexpr bool NOPIPE = (ABL & 256) != 0;  // no S double buffer: fewer VGPRs, three waves per SIMD (implies asm DMA)
   constexpr bool DMA = (ABL & (64 | 128 | 256)) != 0;    // global->LDS staging by LDS-DMA (buffer_load ... lds), no registers (real variant)
-  constexpr bool HOIST = (ABL & (32 | 512)) != 0;  // issue the K fragment reads a phase early (real variant)
-  constexpr bool HOIST_V = (ABL & 32) != 0;        // ... and the V fragment reads too
   auto load_kf = [&](v8 (&kf0)[4], v8 (&kf1)[4], int kslot) {
     const unsigned char* Kb = smem + K_OFF + kslot * TILE_BYTES;
 #pragma unroll
@@ -245,15 +240,6 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
     load_kf(kf0, kf1, kslot);
     qk_mfma(s0, s1, kf0, kf1);
   };
-  auto load_vf = [&](v8 (&vf0)[4], v8 (&vf1)[4], const unsigned char* Vb) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {  // j = 2*kb + ks
-      const int off = (32 * (j >> 1) + 16 * (j & 1)) * 128;
-      vf0[j] = join_tr<v8>(lds_read_tr16(Vb + vread[0] + off), lds_read_tr16(Vb + vread[0] + off + 8 * 128));
-      vf1[j] = join_tr<v8>(lds_read_tr16(Vb + vread[1] + off), lds_read_tr16(Vb + vread[1] + off + 8 * 128));
-    }
-  };
-
   // Fold the current segment's accumulators into the lazily scaled LDS total:
   //   total = total * 2^((m_ot - m_run) c) + O_seg o a_seg + rowsum(P_seg) * b_seg
   // (a = 1, b = 0 for the self segment).  Linear in the keys, so folding a PART of a segment (a
@@ -316,11 +302,6 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
         if (key + 32 >= valid) c1[r] = -INFINITY;
       }
     }
-    v8 kf0[4], kf1[4], vf0[4], vf1[4];
-    if (HOIST) {  // K fragments of tile t+1 fly while the max chain runs
-      if (has1) load_kf(kf0, kf1, (t + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
     // (2) row max of S(t): two v_max3 chains + one cross-half exchange
     float mxa = max3(c0[0], c0[1], c0[2]);
     float mxb = max3(c1[0], c1[1], c1[2]);
@@ -345,21 +326,13 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
       lb *= alpha;
       m_run = m_new;
     }
-    if (ABL & 2048) __builtin_amdgcn_s_setprio(1);  // matrix-heavy phase wins arbitration (experiment)
     // (4) the overlapped block: prefetch issue, S(t+1) on the matrix pipe, exp/pack on the VALU,
     //     PV(t) on the matrix pipe
-    if (HOIST_V) {  // V fragments of tile t fly under the QK^T MFMAs and the exp work
-      load_vf(vf0, vf1, Vb);
-      __builtin_amdgcn_sched_barrier(0);
-    }
     if (!NOPIPE && has2 && !(ABL & 4)) {
       if (DMA) issue_dma(t & 1, (vcur >= 1) ? vcur - 1 : 2);  // K slot (t+2)&1, V slot (vcur+2)%3: both free since the last barrier
       else issue_loads();
     }
-    if (!NOPIPE && has1) {
-      if (HOIST) qk_mfma(n0, n1, kf0, kf1);
-      else qk(n0, n1, (t + 1) & 1);
-    }
+    if (!NOPIPE && has1) qk(n0, n1, (t + 1) & 1);
     const f32x2 cc = {c2, c2};
     const f32x2 nm = {-mc, -mc};
     if (!(ABL & 8))
@@ -386,10 +359,7 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int off = (32 * kb + 16 * ks) * 128;
-        if (HOIST_V) {
-          o0 = Tr::mfma(vf0[2 * kb + ks], pk[kb][ks], o0);
-          o1 = Tr::mfma(vf1[2 * kb + ks], pk[kb][ks], o1);
-        } else if (ABL & 16) {
+        if (ABL & 16) {
           o0 = Tr::mfma(qf[kb + ks], pk[kb][ks], o0);
           o1 = Tr::mfma(qf[3 - kb - ks], pk[kb][ks], o1);
         } else {
@@ -420,7 +390,6 @@ __global__ void __launch_bounds__(NW * 64, (ABL & 256) ? 3 : 2) shared_attn_fwd_
       }
       advance();
     }
-    if (ABL & 2048) __builtin_amdgcn_s_setprio(0);
     if (DMA_ASM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // our DMA of pair t+2 has landed
     if (!(ABL & 1)) __syncthreads();
   };
@@ -592,7 +561,7 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.nqb = (p.Lq + QB - 1) / QB;
   p.sk_items = p.B * p.H * p.nqb;
   p.sk_ix = (p.sk_items + 7) / 8;
-  const int slots_x = 32 * (NW == 8 ? 1 : ((ABL & 256) ? 3 : 2));
+  const int slots_x = 32 * (NW == 8 ? 1 : (((ABL & 256) && !FOLD) ? 3 : 2));
   int full = (p.sk_ix / slots_x) * slots_x;
   int rem = p.sk_ix - full;
   int k = 1;
@@ -622,12 +591,8 @@ template <typename T>
 hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   const bool fold = (p.aa != nullptr);
   if (nw == 8) return fold ? launch<T, 8, true>(p, s) : launch<T, 8, false>(p, s);
-  if (nw == 5) return fold ? launch<T, 4, true, 32>(p, s) : launch<T, 4, false, 32>(p, s);  // hoisted LDS reads
   if (nw == 6) return fold ? launch<T, 4, true, 64>(p, s) : launch<T, 4, false, 64>(p, s);  // LDS-DMA staging
   if (nw == 7) return fold ? launch<T, 4, true, 128>(p, s) : launch<T, 4, false, 128>(p, s);  // LDS-DMA from asm
-  if (nw == 10) return fold ? launch<T, 4, true, 128 | 512>(p, s) : launch<T, 4, false, 128 | 512>(p, s);  // asm DMA + K fragments hoisted
-  if (nw == 11) return fold ? launch<T, 4, true, 128 | 1024>(p, s) : launch<T, 4, false, 128 | 1024>(p, s);  // + static setprio
-  if (nw == 12) return fold ? launch<T, 4, true, 128 | 2048>(p, s) : launch<T, 4, false, 128 | 2048>(p, s);  // + phase setprio
   if (nw == 9) return fold ? launch<T, 4, true, 256>(p, s) : launch<T, 4, false, 256>(p, s);  // straight schedule, 3 waves/SIMD
   return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
 }

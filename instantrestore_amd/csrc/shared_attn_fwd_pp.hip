@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(512, 2) shared_attn_fwd_pp_kernel(const AttnKP
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
   using v4 = typename Tr::v4;
-  constexpr int NW = 8, NT = 512, QB = 256;
+  constexpr int NT = 512, QB = 256;  // 8 waves
   constexpr int K_OFF = 0;                      // K ring: 3 tiles
   constexpr int V_OFF = 3 * TILE_BYTES;         // V ring: 3 tiles
   constexpr int OT_OFF = 6 * TILE_BYTES;        // folded total: 32 floats per thread

@@ -201,6 +201,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
   float m_ot = -INFINITY;                   // FOLD: the running max the LDS total is scaled to
   float m_run = -INFINITY;
   const float c2 = p.scale_log2;
+  const float lazy_thr = 6.0f / c2;  // LAZYMAX: raw-score growth that forces a rescale
   const int NTILES = tile_end - tile_begin;  // tiles of THIS piece (all of them when not split)
 
   // PV/softmax stream position (the QK^T of tile t+1 is issued unmasked; masking happens when a
@@ -316,16 +317,18 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
       mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), mx);
     }
     const float m_new = max3(m_run, mx, mx);
-    const float mc = m_new * c2;
-    // (3) rescale only when some row's max moved (exact)
-    if (__any(m_new != m_run)) {
-      const float alpha = fast_exp2(m_run * c2 - mc);
+    // (3) rescale only when some row's max moved (exact).  LAZYMAX (experiment): keep the old
+    // reference while no row's max grew by more than 2^6 in the exp2 domain, so P <= 64.
+    constexpr bool LAZYMAX = (ABL & 1024) != 0;
+    if (LAZYMAX ? __any(mx > m_run + lazy_thr) : __any(m_new != m_run)) {
+      const float alpha = fast_exp2((m_run - m_new) * c2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
       la *= alpha;
       lb *= alpha;
       m_run = m_new;
     }
+    const float mc = (LAZYMAX ? m_run : m_new) * c2;
     // (4) the overlapped block: prefetch issue, S(t+1) on the matrix pipe, exp/pack on the VALU,
     //     PV(t) on the matrix pipe
     if (!NOPIPE && has2 && !(ABL & 4)) {
@@ -593,6 +596,7 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   if (nw == 8) return fold ? launch<T, 8, true>(p, s) : launch<T, 8, false>(p, s);
   if (nw == 6) return fold ? launch<T, 4, true, 64>(p, s) : launch<T, 4, false, 64>(p, s);  // LDS-DMA staging
   if (nw == 7) return fold ? launch<T, 4, true, 128>(p, s) : launch<T, 4, false, 128>(p, s);  // LDS-DMA from asm
+  if (nw == 10) return fold ? launch<T, 4, true, 128 | 1024>(p, s) : launch<T, 4, false, 128 | 1024>(p, s);  // asm DMA + lazy max
   if (nw == 9) return fold ? launch<T, 4, true, 256>(p, s) : launch<T, 4, false, 256>(p, s);  // straight schedule, 3 waves/SIMD
   return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
 }

@@ -8,6 +8,8 @@ from instantrestore_amd import ops
 from oracle import shared_attn_oracle as O
 torch.manual_seed(0)
 B, H, L, N = 1, 2, 1024, 4
+VARIANT = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+ops.set_attn_variant(VARIANT)
 C = H * 64
 for dtype, name in ((torch.float16, "fp16"), (torch.bfloat16, "bf16")):
     for scale_in, tag in ((1.0, "N(0,1)"), (0.25, "N(0,1/16)")):

@@ -270,13 +270,14 @@ FULL = [
     (4096, 5, 4, torch.bfloat16, True),
     (4096, 5, 4, torch.float16, False),
     (1024, 10, 8, torch.bfloat16, True),
+    (16384, 5, 4, torch.float16, True),   # config 5: 1024 px, Lkv = 81920 (the largest layer in BASELINE.json)
 ]
 
 
-@pytest.mark.parametrize("L,H,N,dtype,inc", FULL, ids=["L4096N4bf16t1", "L4096N4f16t0", "L1024N8bf16t1"])
+@pytest.mark.parametrize("L,H,N,dtype,inc", FULL, ids=["L4096N4bf16t1", "L4096N4f16t0", "L1024N8bf16t1", "L16384N4f16t1"])
 def test_full_size_layer_sampled_rows_and_properties(ops, L, H, N, dtype, inc):
     gen = torch.Generator().manual_seed(4242)
-    B, C = 2, H * 64
+    B, C = (1 if L > 4096 else 2), H * 64
     q, k = _rand((B, L, C), dtype, gen), _rand((B, L, C), dtype, gen)
     v = _rand((B, L, C), dtype, gen, 0.9, 0.3)
     rk, rv = _rand((B, N, L, C), dtype, gen), _rand((B, N, L, C), dtype, gen, 1.4, -0.2)

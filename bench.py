@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--train-input", type=int, default=1, help="1: self K/V precede the reference K/V (t=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B (ir_set_attn_variant); 0 = default")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -215,6 +216,9 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     train_input = bool(args.train_input)
+    if args.variant:
+        from instantrestore_amd import ops as _ops
+        _ops.set_attn_variant(args.variant)
     layers, (B, N, px, dtype, use_adain) = build_workload(args.config, train_input, dev, seed=1234 + rank)
 
     def barrier():

@@ -1,0 +1,340 @@
+// shared_attn_fwd_w64.hip - 64-query-rows-per-wave variant of the fused extended self-attention
+// forward (gfx950), no AdaIN fold.  Same math, layouts and C-ABI contract as the other kernels.
+//
+// Why: ablation of the pipelined kernel attributes ~20 % of its time to LDS fragment reads and
+// ~10 % to staging + barriers - costs that are paid per wave per K/V tile.  Here every wave owns
+// TWO 32-row blocks (A, B): each K fragment fetched from LDS feeds the QK^T MFMAs of both blocks,
+// each V^T fragment feeds both PV MFMAs, and a 4-wave workgroup covers 256 rows, so fragment
+// reads, DMA traffic and barriers per flop are all halved.  Straight schedule (no S double
+// buffer - the registers go to the second block), asm-issued LDS-DMA one tile ahead, K/V rings of 2.
+#include <type_traits>
+
+#include "ir_common.h"
+#include "ir_kernels.h"
+
+namespace {
+
+constexpr int KVB = IR_KV_TILE;
+constexpr int TILE_BYTES = KVB * 64 * 2;  // 8 KiB
+
+struct RowBlock {
+  f32x16 o0, o1;     // O^T accumulators (d = 32*db + crow(r,hi), column = query row)
+  f32x2 la, lb;      // partial row sums
+  float m_run;       // running (lazy) max of the raw scores
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnKParams p) {
+  using Tr = ElemTraits<T>;
+  using v8 = typename Tr::v8;
+  using v4 = typename Tr::v4;
+  constexpr int NW = 4, NT = 256, QB = 256, CH = 2;
+  constexpr int K_OFF = 0, V_OFF = 2 * TILE_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hi = lane >> 5, lq = lane & 31;
+
+  // ---- work decode (whole items, then K/V-range pieces of the remainder items) -------------------
+  const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
+  int item_local, piece = 0, npiece = 1;
+  if (xslot < p.sk_full) {
+    item_local = xslot;
+  } else {
+    npiece = p.sk_k;
+    const int r = xslot - p.sk_full;
+    item_local = p.sk_full + r / npiece;
+    piece = r - (r / npiece) * npiece;
+  }
+  const int lin = xcd * p.sk_ix + item_local;
+  if (item_local >= p.sk_ix || lin >= p.sk_items) return;
+  const int tile_begin = (int)(((long)p.ntiles * piece) / npiece);
+  const int tile_end = (int)(((long)p.ntiles * (piece + 1)) / npiece);
+  const int NTILES = tile_end - tile_begin;
+  const int bh = lin / p.nqb, qb = lin - bh * p.nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  // ---- Q fragments of both row blocks -----------------------------------------------------------
+  const int qrowA = qb * QB + wid * 64 + lq, qrowB = qrowA + 32;
+  v8 qA[4], qB[4];
+  {
+    const int ra = qrowA < p.Lq ? qrowA : p.Lq - 1, rb = qrowB < p.Lq ? qrowB : p.Lq - 1;
+    const T* base = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qA[ks] = *(const v8*)(base + (int64_t)ra * p.q_sl + ks * 16);
+      qB[ks] = *(const v8*)(base + (int64_t)rb * p.q_sl + ks * 16);
+    }
+  }
+
+  int kread[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kread[ks] = lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4);
+  int vread[2];
+  {
+    const int m = lane & 15, g = (lane >> 4) & 1;
+    const int sw = (m >> 3) & 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+      vread[db] = (4 * hi + (m >> 2)) * 128 + ((db ^ sw) << 6) + 32 * g + 8 * (m & 3);
+  }
+
+  // ---- DMA stream (lane-linear LDS image, swizzle on the source slot) ------------------------------
+  const int pslot = tid & 7;
+  int srow[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) srow[c] = (tid >> 3) + c * (NT / 8);
+  const int nseg = p.include_self + p.N;
+  i32x4 krw = {0, 0, 0, 0}, vrw = {0, 0, 0, 0};
+  int kstep = 0, vstep = 0, sntile = 0, seg = 0, t0 = 0;
+  unsigned kvo[CH], vvo[CH];
+  auto seg_setup = [&](int s) {
+    const T* sk;
+    const T* sv;
+    int ksl_b, vsl_b, slen;
+    if (p.include_self && s == 0) {
+      sk = (const T*)p.k_self + (int64_t)b * p.ks_sb + (int64_t)h * p.ks_sh;
+      sv = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
+      ksl_b = (int)p.ks_sl * 2; vsl_b = (int)p.vs_sl * 2; slen = p.Ls; sntile = p.tiles_self;
+    } else {
+      const int n = s - p.include_self;
+      sk = (const T*)p.k_ref + (int64_t)b * p.kr_sb + (int64_t)n * p.kr_sn + (int64_t)h * p.kr_sh;
+      sv = (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)n * p.vr_sn + (int64_t)h * p.vr_sh;
+      ksl_b = (int)p.kr_sl * 2; vsl_b = (int)p.vr_sl * 2; slen = p.Lr; sntile = p.tiles_ref;
+    }
+    krw = make_rsrc_words(sk, (unsigned)((slen - 1) * ksl_b + 128));
+    vrw = make_rsrc_words(sv, (unsigned)((slen - 1) * vsl_b + 128));
+    kstep = KVB * ksl_b;
+    vstep = KVB * vsl_b;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      kvo[c] = (unsigned)(srow[c] * ksl_b + ((pslot ^ ((srow[c] >> 1) & 7)) * 16));
+      vvo[c] = (unsigned)(srow[c] * vsl_b + ((pslot ^ (((srow[c] >> 1) & 1) << 2)) * 16));
+    }
+  };
+  auto issue_pair = [&](int slot2) {
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      buffer_load_lds16_async(krw, smem + K_OFF + slot2 * TILE_BYTES + (c * NW + wid) * 1024, kvo[c]);
+      buffer_load_lds16_async(vrw, smem + V_OFF + slot2 * TILE_BYTES + (c * NW + wid) * 1024, vvo[c]);
+      kvo[c] += kstep;
+      vvo[c] += vstep;
+    }
+    if (++t0 == sntile) {
+      t0 = 0;
+      if (++seg < nseg) seg_setup(seg);
+    }
+  };
+
+  // ---- state ------------------------------------------------------------------------------------
+  RowBlock A, Bk;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { A.o0[r] = 0.f; A.o1[r] = 0.f; Bk.o0[r] = 0.f; Bk.o1[r] = 0.f; }
+  A.la = A.lb = Bk.la = Bk.lb = f32x2{0.f, 0.f};
+  A.m_run = Bk.m_run = -INFINITY;
+  const float c2 = p.scale_log2;
+  const float lazy_thr = 6.0f / c2;
+
+  int seg_b = 0, t0_b = tile_begin;
+  if (!(p.include_self && tile_begin < p.tiles_self)) {
+    const int r = tile_begin - p.tiles_self;
+    seg_b = p.include_self + r / p.tiles_ref;
+    t0_b = r - (r / p.tiles_ref) * p.tiles_ref;
+  }
+  int ct0 = t0_b;
+  const bool first_is_self = (p.include_self && seg_b == 0);
+  int c_ntile = first_is_self ? p.tiles_self : p.tiles_ref;
+  int c_len = first_is_self ? p.Ls : p.Lr;
+
+  // softmax step of one row block on (s0, s1) -> pk
+  auto softmax = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], int valid) {
+    if (valid < KVB) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key >= valid) s0[r] = -INFINITY;
+        if (key + 32 >= valid) s1[r] = -INFINITY;
+      }
+    }
+    float mxa = max3(s0[0], s0[1], s0[2]);
+    float mxb = max3(s1[0], s1[1], s1[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) {
+      mxa = max3(mxa, s0[r], s0[r + 1]);
+      mxb = max3(mxb, s1[r], s1[r + 1]);
+    }
+    float mx = max3(mxa, mxb, max3(s0[15], s1[15], s1[15]));
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), mx);
+    }
+    if (__any(mx > R.m_run + lazy_thr)) {  // lazy max: keep the reference while P stays <= 2^6
+      const float m_new = max3(R.m_run, mx, mx);
+      const float alpha = fast_exp2((R.m_run - m_new) * c2);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { R.o0[r] *= alpha; R.o1[r] *= alpha; }
+      R.la *= alpha;
+      R.lb *= alpha;
+      R.m_run = m_new;
+    }
+    const float mc = R.m_run * c2;
+    const f32x2 cc = {c2, c2};
+    const f32x2 nm = {-mc, -mc};
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      f32x2 t0v = {s0[r], s0[r + 1]};
+      f32x2 t1v = {s1[r], s1[r + 1]};
+      t0v = __builtin_elementwise_fma(t0v, cc, nm);
+      t1v = __builtin_elementwise_fma(t1v, cc, nm);
+      t0v[0] = fast_exp2(t0v[0]); t0v[1] = fast_exp2(t0v[1]);
+      t1v[0] = fast_exp2(t1v[0]); t1v[1] = fast_exp2(t1v[1]);
+      R.la += t0v;
+      R.lb += t1v;
+      s0[r] = t0v[0]; s0[r + 1] = t0v[1];
+      s1[r] = t1v[0]; s1[r + 1] = t1v[1];
+    }
+    pk[0][0] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+    pk[0][1] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+    pk[1][0] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+    pk[1][1] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+  };
+
+  // ---- prologue ---------------------------------------------------------------------------------
+  seg = seg_b;
+  t0 = t0_b;
+  seg_setup(seg);
+#pragma unroll
+  for (int c = 0; c < CH; ++c) { kvo[c] += (unsigned)(t0 * kstep); vvo[c] += (unsigned)(t0 * vstep); }
+  issue_pair(0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qA[ks]), "v"(qB[ks]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int t = 0; t < NTILES; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < NTILES) issue_pair(cur ^ 1);  // pair t+1: its slot was last read in step t-1
+
+    // ---- S^T = K Q^T for both row blocks: every K fragment is fetched once, used twice ----------
+    const unsigned char* Kb = smem + K_OFF + cur * TILE_BYTES;
+    f32x16 sa0, sa1, sb0, sb1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const v8 k0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks]);
+      const v8 k1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks]);
+      sa0 = Tr::mfma(k0, qA[ks], sa0);
+      sa1 = Tr::mfma(k1, qA[ks], sa1);
+      sb0 = Tr::mfma(k0, qB[ks], sb0);
+      sb1 = Tr::mfma(k1, qB[ks], sb1);
+    }
+    asm volatile("s_nop 7\n\ts_nop 4" : "+v"(sa0), "+v"(sa1), "+v"(sb0), "+v"(sb1));  // MFMA -> asm v_max3 pad
+
+    const int valid = c_len - ct0 * KVB;
+    v8 pkA[2][2], pkB[2][2];
+    softmax(A, sa0, sa1, pkA, valid);
+    softmax(Bk, sb0, sb1, pkB, valid);
+
+    // ---- O^T += V^T P^T for both row blocks: every V^T fragment is fetched once, used twice -----
+    const unsigned char* Vb = smem + V_OFF + cur * TILE_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = (32 * kb + 16 * ks) * 128;
+        const v8 v0 = join_tr<v8>(lds_read_tr16(Vb + vread[0] + off), lds_read_tr16(Vb + vread[0] + off + 8 * 128));
+        const v8 v1 = join_tr<v8>(lds_read_tr16(Vb + vread[1] + off), lds_read_tr16(Vb + vread[1] + off + 8 * 128));
+        A.o0 = Tr::mfma(v0, pkA[kb][ks], A.o0);
+        A.o1 = Tr::mfma(v1, pkA[kb][ks], A.o1);
+        Bk.o0 = Tr::mfma(v0, pkB[kb][ks], Bk.o0);
+        Bk.o1 = Tr::mfma(v1, pkB[kb][ks], Bk.o1);
+      }
+    }
+    if (++ct0 == c_ntile) { ct0 = 0; c_ntile = p.tiles_ref; c_len = p.Lr; }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pair t+1 has landed
+    __syncthreads();
+  }
+
+  // ---- epilogue (per row block) ---------------------------------------------------------------------
+  auto finish = [&](RowBlock& R, int qrow, int rowoff) {
+    float ls = (R.la[0] + R.la[1]) + (R.lb[0] + R.lb[1]);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+    const float l_fin = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    if (npiece > 1) {
+      const int64_t prow = ((int64_t)((xcd * (p.sk_ix - p.sk_full) + (item_local - p.sk_full)) * npiece + piece)) * QB + wid * 64 + rowoff + lq;
+      float* wo = p.ws_o + prow * 64;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 x0, x1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x0[i] = R.o0[4 * g4 + i]; x1[i] = R.o1[4 * g4 + i]; }
+        *(f32x4*)(wo + 8 * g4 + 4 * hi) = x0;
+        *(f32x4*)(wo + 32 + 8 * g4 + 4 * hi) = x1;
+      }
+      if (hi == 0) {
+        p.ws_ml[prow * 2] = R.m_run;
+        p.ws_ml[prow * 2 + 1] = l_fin;
+      }
+      return;
+    }
+    const float inv = 1.0f / l_fin;
+    if (qrow < p.Lq) {
+      T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 x0, x1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x0[i] = R.o0[4 * g4 + i] * inv; x1[i] = R.o1[4 * g4 + i] * inv; }
+        *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
+        *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
+      }
+      if (p.lse != nullptr && hi == 0)
+        p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = R.m_run * p.scale + __logf(l_fin);
+    }
+  };
+  finish(A, qrowA, 0);
+  finish(Bk, qrowB, 32);
+}
+
+template <typename T>
+hipError_t launch(const AttnKParams& p0, hipStream_t s) {
+  AttnKParams p = p0;
+  constexpr int QB = 256;
+  p.nqb = (p.Lq + QB - 1) / QB;
+  p.sk_items = p.B * p.H * p.nqb;
+  p.sk_ix = (p.sk_items + 7) / 8;
+  const int slots_x = 64;  // two 4-wave workgroups per CU
+  int full = (p.sk_ix / slots_x) * slots_x;
+  int rem = p.sk_ix - full;
+  int k = 1;
+  if (p.ws != nullptr && rem > 0) {
+    k = slots_x / rem;
+    const int kmax = p.ntiles / 8;
+    if (k > kmax) k = kmax;
+    const size_t piece_bytes = (size_t)QB * 66 * sizeof(float);
+    const size_t cap = p.ws_bytes / piece_bytes;
+    if ((size_t)8 * rem * k > cap) k = (int)(cap / ((size_t)8 * rem));
+    if (k < 1) k = 1;
+  }
+  if (k <= 1) { full = p.sk_ix; rem = 0; k = 1; }
+  p.sk_full = full;
+  p.sk_k = k;
+  p.ws_o = p.ws;
+  p.ws_ml = p.ws + (size_t)8 * rem * k * QB * 64;
+  const int grid = 8 * (full + rem * k);
+  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T>), dim3(grid), dim3(256), 0, s, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || k <= 1) return e;
+  return ir_launch_shared_attn_combine(p, std::is_same<T, __bf16>::value ? 1 : 0, QB, rem, s);
+}
+
+}  // namespace
+
+// no AdaIN fold in this kernel: callers materialise V' first (ir_adain_apply) or pass no affine
+hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s) {
+  return dtype == 1 ? launch<__bf16>(p, s) : launch<_Float16>(p, s);
+}

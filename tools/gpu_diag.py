@@ -37,7 +37,7 @@ def onehot_case(dtype, L, N, Lr, inc, variant):
 def main():
     print(torch.cuda.get_device_name(0), ops._lib.lib().ir_build_info().decode())
     ok = True
-    for variant in (0, 1, 2, 3, 4, 6, 7, 8, 9):
+    for variant in (0, 1, 2, 3, 4, 6, 7, 8, 9, 12):
         for dtype in (torch.float16, torch.bfloat16):
             ok &= onehot_case(dtype, 64, 0, 0, True, variant)
             ok &= onehot_case(dtype, 256, 2, 128, True, variant)

@@ -441,3 +441,31 @@ def test_hip_graph_capture_and_replay(ops):
         torch.cuda.synchronize()
         want = attn(x, ref_keys=rk, ref_values=rv)
     assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize("variant", [0, 7, 12])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+def test_absolute_accuracy_on_unit_normal_activations(ops, dtype, variant, capsys):
+    """BASELINE.json's north_star tolerance is 'max-abs 1e-3' on the attention output; it is
+    meaningful for O(1) activations, so measure it there: N(0,1) q/k/v/references at the 32x32
+    layer length with AdaIN and the self segment on, against the float64 oracle.  fp16 must be
+    inside 1e-3 absolute; bf16 (8 mantissa bits: one rounding of an O(1) output is already 2e-3)
+    must stay inside its own output rounding, 1e-3 is reported but not asserted."""
+    torch.manual_seed(0)
+    B, H, L, N = 1, 2, 1024, 4
+    C = H * 64
+    q, k, v = (torch.randn(B, L, C).to(dtype) for _ in range(3))
+    rk, rv = torch.randn(B, N, L, C).to(dtype), torch.randn(B, N, L, C).to(dtype)
+    ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.125, True, True)
+    c = lambda t: t.cuda()
+    ops.set_attn_variant(variant)
+    try:
+        aff = ops.adain_stats(c(v), c(rv), heads=H)
+        out = ops.shared_attention(c(q), c(k), c(v), c(rk), c(rv), heads=H, scale=0.125, include_self=True, adain=aff)
+    finally:
+        ops.set_attn_variant(0)
+    err = np.abs(out.float().cpu().numpy().astype(np.float64) - ref)
+    with capsys.disabled():
+        print(f"\n[accuracy] variant {variant} {dtype}: max|O| {np.abs(ref).max():.3f} max|err| {err.max():.2e} mean|err| {err.mean():.2e}")
+    bound = 1e-3 if dtype == torch.float16 else 2.0 ** -8 * max(1.0, np.abs(ref).max())
+    assert err.max() <= bound, (err.max(), bound)

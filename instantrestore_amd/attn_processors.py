@@ -21,6 +21,7 @@ from typing import List, Optional
 import torch
 from torch import nn
 
+from . import lora_fold as _lora
 from . import ops as _ops  # tests swap this module-level name for an oracle-backed stand-in
 
 
@@ -82,7 +83,7 @@ def _kv_source(attn, st: _Prepared) -> torch.Tensor:
 
 
 def _epilogue(attn, st: _Prepared, tokens: torch.Tensor) -> torch.Tensor:
-    out = attn.to_out[0](tokens)   # linear proj (LoRA-wrapped on the main UNet)
+    out = _project_out(attn, tokens)   # linear proj (LoRA-wrapped on the main UNet)
     out = attn.to_out[1](out)      # dropout (p = 0)
     if st.ndim == 4:
         bsz, ch, hh, ww = st.shape4
@@ -94,41 +95,54 @@ def _epilogue(attn, st: _Prepared, tokens: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _autocast_or(weight: torch.Tensor, x: torch.Tensor) -> torch.dtype:
+    if x.is_cuda and torch.is_autocast_enabled("cuda"):
+        return torch.get_autocast_dtype("cuda")
+    return weight.dtype
+
+
 def _project_qkv(attn, st: _Prepared):
     """``to_q`` / ``to_k`` / ``to_v`` of the reference (attn_processors.py:222-230).
 
-    Self-attention with three plain bias-free ``nn.Linear`` projections of equal shape runs them
-    as ONE GEMM against a cached concatenation of the three weights (SURVEY.md section 8f rank
-    4): the fused attention kernel reads q / k / v as strided views of that single ``(B, L, 3C)``
-    result, so nothing is copied.  Same values as three separate calls (each output column is
-    the same dot product).  Anything else - cross attention, peft/LoRA-wrapped or biased
-    projections, training - takes the three module calls exactly like the reference."""
+    Self-attention whose three projections are bias-free linear maps of equal shape - plain
+    ``nn.Linear`` or peft LoRA wrappers in inference state (``lora_fold``) - runs them as ONE
+    GEMM against a cached concatenation of the three (LoRA-folded) weights (SURVEY.md section
+    8f rank 4): the fused attention kernel reads q / k / v as strided views of that single
+    ``(B, L, 3C)`` result, so nothing is copied.  Same values as three separate calls for plain
+    projections (each output column is the same dot product); for LoRA wrappers the adapter is
+    merged exactly as peft's ``merge_and_unload`` does.  Anything else - cross attention, biased
+    projections, active dropout, DoRA, training - takes the three module calls like the
+    reference."""
     src = _kv_source(attn, st)
     tq, tk, tv = attn.to_q, attn.to_k, attn.to_v
-    fusable = (
-        st.encoder is None
-        and type(tq) is nn.Linear and type(tk) is nn.Linear and type(tv) is nn.Linear
-        and tq.bias is None and tk.bias is None and tv.bias is None
-        and tq.weight.shape == tk.weight.shape == tv.weight.shape
-        and not torch.is_grad_enabled()
-    )
-    if not fusable:
+    if st.encoder is not None or torch.is_grad_enabled():
         return tq(st.hidden), tk(src), tv(src)
-    if st.hidden.is_cuda and torch.is_autocast_enabled("cuda"):
-        dtype = torch.get_autocast_dtype("cuda")
-    else:
-        dtype = tq.weight.dtype
-    key = (tq.weight.data_ptr(), tk.weight.data_ptr(), tv.weight.data_ptr(),
-           tq.weight._version, tk.weight._version, tv.weight._version, dtype, tq.weight.device)
-    cache = attn.__dict__.get("_ir_qkv_cache")  # plain attribute: never part of the state dict
-    if cache is None or cache[0] != key:
-        w = torch.cat([tq.weight.detach(), tk.weight.detach(), tv.weight.detach()], dim=0).to(dtype)
-        cache = (key, w)
-        attn.__dict__["_ir_qkv_cache"] = cache
+    effs = [_lora.effective_linear(m) for m in (tq, tk, tv)]
+    if any(e is None or e[0].bias is not None for e in effs) or \
+            not (effs[0][0].weight.shape == effs[1][0].weight.shape == effs[2][0].weight.shape):
+        return tq(st.hidden), tk(src), tv(src)
+    dtype = _autocast_or(effs[0][0].weight, st.hidden)
+    w = _lora.cached_weight(attn, "_ir_qkv_cache", (tq, tk, tv), dtype)
     x = st.hidden if st.hidden.dtype == dtype else st.hidden.to(dtype)
-    qkv = torch.nn.functional.linear(x, cache[1])
-    c = tq.weight.shape[0]
+    qkv = torch.nn.functional.linear(x, w)
+    c = w.shape[0] // 3
     return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+
+
+def _project_out(attn, tokens: torch.Tensor) -> torch.Tensor:
+    """``to_out[0]`` (attn_processors.py:267): one GEMM also when the module is a LoRA wrapper in
+    inference state; the module call itself otherwise (plain ``nn.Linear`` included)."""
+    proj = attn.to_out[0]
+    if type(proj) is nn.Linear or torch.is_grad_enabled():
+        return proj(tokens)
+    eff = _lora.effective_linear(proj)
+    if eff is None:
+        return proj(tokens)
+    dtype = _autocast_or(eff[0].weight, tokens)
+    w = _lora.cached_weight(attn, "_ir_out_cache", (proj,), dtype)
+    bias = eff[0].bias
+    x = tokens if tokens.dtype == dtype else tokens.to(dtype)
+    return torch.nn.functional.linear(x, w, None if bias is None else bias.to(dtype))
 
 
 def _same_16bit(q: torch.Tensor, *others: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define IR_ABI_VERSION 2
+#define IR_ABI_VERSION 3
 #define IR_HEAD_DIM 64
 
 typedef enum ir_status {
@@ -191,6 +191,59 @@ int ir_zero_invalid_refs(int32_t batch, int32_t heads, int32_t n_refs, int32_t l
  */
 int ir_tensor2im_u8(int32_t dtype, int32_t batch, int32_t channels, int32_t height, int32_t width, const void* x,
                     int64_t x_sb, int64_t x_sc, int64_t x_sh, int64_t x_sw, void* out_u8, void* stream);
+
+/*
+ * ir_preprocess_lanczos_u8 - the caller's input transform on the device.
+ *
+ * Replaces, for a batch of differently sized RGB images, the per-image CPU pipeline of
+ * face_replace/inference/test.py:54-59 (applied at :76, :127, :150):
+ *     Resize(size, LANCZOS) -> CenterCrop(size) -> ToTensor() -> Normalize(0.5, 0.5)
+ * i.e. Pillow's 8-bit two-pass resampler (pillow==10.4.0 Resample.c; horizontal pass rounded to
+ * uint8, then vertical, 22-bit fixed-point taps) and (v/255 - 0.5)/0.5 in float32, cast to
+ * out_dtype.  The resampled bytes are bit-identical to Pillow's; only the crop is computed.
+ *
+ * The tap tables are Pillow's precompute_coeffs + normalize_coeffs_8bpc, produced on the HOST by
+ * ir_lanczos_ksize / ir_lanczos_coeffs (no GPU involved; same libm and operation order) and uploaded
+ * by the caller once per (in_size, out_size); out sizes and crop offsets follow torchvision 0.15.2
+ * (instantrestore_amd/preprocess.py).
+ *   images: HOST array of n descriptors; every pointer inside is a DEVICE pointer
+ *   out   : (n, 3, size, size) contiguous, dtype 0 = fp16, 1 = bf16, 2 = fp32
+ */
+typedef struct ir_image_desc {
+  const void* src;          /* (in_h, in_w, 3) uint8, rows src_row_bytes apart */
+  int64_t src_row_bytes;
+  int32_t in_h, in_w;
+  int32_t out_h, out_w;     /* resized size (before the crop) */
+  int32_t crop_top, crop_left;
+  const int32_t* bounds_h;  /* (out_w, 2) */
+  const int32_t* kk_h;      /* (out_w, ksize_h) */
+  const int32_t* bounds_v;  /* (out_h, 2) */
+  const int32_t* kk_v;      /* (out_h, ksize_v) */
+  int32_t ksize_h, ksize_v;
+  int32_t row_first, row_count; /* source rows touched by the vertical taps of the crop's rows */
+  void* tmp;                /* >= row_count * size * 3 bytes of scratch for this image */
+} ir_image_desc;
+
+int ir_lanczos_ksize(int32_t in_size, int32_t out_size);            /* taps per output sample; < 0 on error */
+int ir_lanczos_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds /* host (out,2) */,
+                      int32_t* kk /* host (out, ksize) */);
+int ir_preprocess_lanczos_u8(const ir_image_desc* images, int32_t n_images, int32_t size, int32_t out_dtype,
+                             void* out, void* stream);
+
+/*
+ * ir_freeu_fourier_filter - FreeU's skip-feature filter.
+ *
+ * Replaces fourier_filter(res_hidden_states.float(), threshold, scale).to(dtype)
+ * (face_replace/models/unet_2d_condition/block.py:3514,3518 -> diffusers==0.24.0
+ * utils/torch_utils.py): fftn -> fftshift -> multiply the (2*threshold)^2 centre bins by `scale`
+ * -> ifftshift -> ifftn -> real.  Computed in closed form (only those bins change): one read of x,
+ * one write of out, fp32 arithmetic, no intermediate tensors.  In place (out == x) is allowed.
+ *   x, out: `planes` = B*C planes of height*width contiguous elements, plane strides in elements
+ *   dtype 0 = fp16, 1 = bf16, 2 = fp32; height*width <= 4096; 1 <= threshold <= min(H,W)/2
+ */
+int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32_t width, const void* x,
+                            int64_t x_plane_stride, void* out, int64_t out_plane_stride, int32_t threshold,
+                            float scale, void* stream);
 
 /* library identity / diagnostics */
 int ir_abi_version(void);                  /* == IR_ABI_VERSION */

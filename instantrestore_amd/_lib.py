@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # IR_LIB_PATH: load an alternative build of the same ABI (compiler-flag A/B experiments)
 LIB_PATH = os.environ.get("IR_LIB_PATH") or os.path.join(_HERE, "libinstantrestore_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 IR_DTYPE_F16, IR_DTYPE_BF16 = 0, 1
 IR_FLAG_INCLUDE_SELF = 1
@@ -35,6 +35,14 @@ class SharedAttnArgs(C.Structure):
     )
 
 
+class ImageDesc(C.Structure):
+    """mirror of ``ir_image_desc`` (one source image of ``ir_preprocess_lanczos_u8``)"""
+
+    _fields_ = [("src", vp), ("src_row_bytes", i64), ("in_h", i32), ("in_w", i32), ("out_h", i32), ("out_w", i32),
+                ("crop_top", i32), ("crop_left", i32), ("bounds_h", vp), ("kk_h", vp), ("bounds_v", vp), ("kk_v", vp),
+                ("ksize_h", i32), ("ksize_v", i32), ("row_first", i32), ("row_count", i32), ("tmp", vp)]
+
+
 # name -> (restype, argtypes); every symbol include/instantrestore_hip.h declares
 SYMBOLS = {
     "ir_abi_version": (C.c_int, []),
@@ -52,6 +60,10 @@ SYMBOLS = {
     "ir_adain_apply": (C.c_int, [i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp,
                                  vp, i64, i64, i64, i64, vp]),
     "ir_tensor2im_u8": (C.c_int, [i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp]),
+    "ir_lanczos_ksize": (C.c_int, [i32, i32]),
+    "ir_lanczos_coeffs": (C.c_int, [i32, i32, vp, vp]),
+    "ir_preprocess_lanczos_u8": (C.c_int, [C.POINTER(ImageDesc), i32, i32, i32, vp, vp]),
+    "ir_freeu_fourier_filter": (C.c_int, [i32, i64, i32, i32, vp, i64, vp, i64, i32, f32, vp]),
     "ir_zero_invalid_refs": (C.c_int, [i32, i32, i32, i32, vp, vp, i64, i64, i64, i64,
                                        vp, i64, i64, i64, i64, vp]),
 }

@@ -247,4 +247,74 @@ int ir_tensor2im_u8(int32_t dtype, int32_t batch, int32_t channels, int32_t heig
   return IR_OK;
 }
 
+int ir_lanczos_ksize(int32_t in_size, int32_t out_size) {
+  if (in_size <= 0 || out_size <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  return ir_host_lanczos_ksize(in_size, out_size);
+}
+
+int ir_lanczos_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* kk) {
+  if (in_size <= 0 || out_size <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (!bounds || !kk) return fail(IR_ERR_INVALID_ARG, "NULL table");
+  ir_host_lanczos_coeffs(in_size, out_size, bounds, kk);
+  return IR_OK;
+}
+
+int ir_preprocess_lanczos_u8(const ir_image_desc* images, int32_t n_images, int32_t size, int32_t out_dtype,
+                             void* out, void* stream) {
+  if (out_dtype < 0 || out_dtype > 2) return fail(IR_ERR_UNSUPPORTED, "out_dtype %d (0 f16, 1 bf16, 2 f32)", out_dtype);
+  if (!images || !out || n_images <= 0 || size <= 0) return fail(IR_ERR_INVALID_ARG, "NULL pointer or empty batch");
+  for (int i = 0; i < n_images; ++i) {
+    const ir_image_desc& d = images[i];
+    if (!d.src || !d.bounds_h || !d.kk_h || !d.bounds_v || !d.kk_v || !d.tmp)
+      return fail(IR_ERR_INVALID_ARG, "image %d: NULL pointer", i);
+    if (d.in_h <= 0 || d.in_w <= 0 || d.src_row_bytes < (int64_t)d.in_w * 3)
+      return fail(IR_ERR_INVALID_ARG, "image %d: bad source geometry", i);
+    if (d.out_h < size || d.out_w < size || d.crop_top < 0 || d.crop_left < 0 || d.crop_top + size > d.out_h ||
+        d.crop_left + size > d.out_w)
+      return fail(IR_ERR_INVALID_ARG, "image %d: crop %dx%d at (%d,%d) outside the %dx%d resized image", i, size, size,
+                  d.crop_top, d.crop_left, d.out_h, d.out_w);
+    if (d.ksize_h <= 0 || d.ksize_v <= 0 || d.row_first < 0 || d.row_count <= 0 || d.row_first + d.row_count > d.in_h)
+      return fail(IR_ERR_INVALID_ARG, "image %d: bad tap tables / row range", i);
+  }
+  for (int first = 0; first < n_images; first += kPreprocessImagesPerLaunch) {
+    PreprocessKParams p;
+    memset(&p, 0, sizeof(p));
+    p.n = n_images - first < kPreprocessImagesPerLaunch ? n_images - first : kPreprocessImagesPerLaunch;
+    p.size = size;
+    p.first_image = first;
+    int max_rows = 0;
+    for (int i = 0; i < p.n; ++i) {
+      const ir_image_desc& d = images[first + i];
+      ResampleImageK& k = p.img[i];
+      k.src = (const unsigned char*)d.src; k.src_row_bytes = d.src_row_bytes;
+      k.bounds_h = d.bounds_h; k.kk_h = d.kk_h; k.bounds_v = d.bounds_v; k.kk_v = d.kk_v;
+      k.tmp = (unsigned char*)d.tmp; k.ksize_h = d.ksize_h; k.ksize_v = d.ksize_v;
+      k.crop_top = d.crop_top; k.crop_left = d.crop_left; k.row_first = d.row_first; k.row_count = d.row_count;
+      if (d.row_count > max_rows) max_rows = d.row_count;
+    }
+    if (max_rows > 65535) return fail(IR_ERR_UNSUPPORTED, "more than 65535 source rows under one crop");
+    const hipError_t e = ir_launch_preprocess(p, max_rows, out_dtype, out, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "preprocess launch: %s", hipGetErrorString(e));
+  }
+  return IR_OK;
+}
+
+int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32_t width, const void* x,
+                            int64_t x_plane_stride, void* out, int64_t out_plane_stride, int32_t threshold,
+                            float scale, void* stream) {
+  if (dtype < 0 || dtype > 2) return fail(IR_ERR_UNSUPPORTED, "dtype %d (0 f16, 1 bf16, 2 f32)", dtype);
+  if (!x || !out) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  if (planes <= 0 || height <= 0 || width <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if ((int64_t)height * width > 4096) return fail(IR_ERR_UNSUPPORTED, "plane %dx%d: at most 4096 elements", height, width);
+  if (threshold < 1 || 2 * threshold > height || 2 * threshold > width)
+    return fail(IR_ERR_INVALID_ARG, "threshold %d outside [1, min(H,W)/2]", threshold);
+  if (x_plane_stride < (int64_t)height * width || out_plane_stride < (int64_t)height * width)
+    return fail(IR_ERR_INVALID_ARG, "plane stride smaller than a plane");
+  if ((planes + 3) / 4 > 0x7fffffffLL) return fail(IR_ERR_UNSUPPORTED, "grid too large");
+  const hipError_t e = ir_launch_freeu_fourier(x, out, dtype, planes, height, width, x_plane_stride, out_plane_stride,
+                                               threshold, scale, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "freeu launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
 }  // extern "C"

@@ -94,3 +94,27 @@ hipError_t ir_launch_adain_apply(const AdainApplyKParams& p, int dtype, hipStrea
 hipError_t ir_launch_zero_refs(const ZeroRefsKParams& p, hipStream_t s);
 hipError_t ir_launch_tensor2im(const void* x, void* out, int dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
                                int B, int C, int H, int W, hipStream_t s);
+
+// ---- image_io.hip: the caller's input transform and FreeU's skip-feature filter ----------------
+struct ResampleImageK {
+  const unsigned char* src;   // (in_h, in_w, 3) uint8, pixel stride 3 bytes
+  int64_t src_row_bytes;
+  const int32_t* bounds_h;    // (out_w, 2): first source column, tap count
+  const int32_t* kk_h;        // (out_w, ksize_h) 22-bit fixed-point taps
+  const int32_t* bounds_v;    // (out_h, 2)
+  const int32_t* kk_v;        // (out_h, ksize_v)
+  unsigned char* tmp;         // (row_count, size, 3): horizontal pass of the crop's columns
+  int32_t ksize_h, ksize_v;
+  int32_t crop_top, crop_left;
+  int32_t row_first, row_count;  // source rows the crop's vertical taps touch
+};
+constexpr int kPreprocessImagesPerLaunch = 16;
+struct PreprocessKParams {
+  ResampleImageK img[kPreprocessImagesPerLaunch];
+  int32_t n, size, first_image;
+};
+hipError_t ir_launch_preprocess(const PreprocessKParams& p, int max_rows, int dtype, void* out, hipStream_t s);
+hipError_t ir_launch_freeu_fourier(const void* x, void* out, int dtype, int64_t planes, int H, int W, int64_t sp_in,
+                                   int64_t sp_out, int thr, float scale, hipStream_t s);
+int ir_host_lanczos_ksize(int in_size, int out_size);
+void ir_host_lanczos_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk);

@@ -313,6 +313,60 @@ def tensor2im_u8(x: torch.Tensor) -> torch.Tensor:
     return out[0] if squeeze else out
 
 
+_ANY_DT = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+
+
+@_on_tensor_device
+def freeu_fourier_filter(x: torch.Tensor, threshold: int, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """FreeU's skip-feature filter on (B, C, H, W) (``ir_freeu_fourier_filter``; replaces
+    ``fourier_filter(x.float(), threshold, scale).to(x.dtype)``, block.py:3514,3518).  Result has
+    ``x``'s dtype; ``out=x`` filters in place."""
+    _need_gpu(x, out)
+    if x.dim() != 4:
+        raise ValueError("expected (B, C, H, W)")
+    code = _ANY_DT.get(x.dtype)
+    if code is None:
+        raise TypeError(f"freeu_fourier_filter: unsupported dtype {x.dtype}")
+    B, Cc, H, W = x.shape
+    if not (x.stride(3) == 1 and x.stride(2) == W and (B == 1 or x.stride(0) == Cc * x.stride(1))):
+        x = x.contiguous()
+    if out is None:
+        out = torch.empty((B, Cc, H, W), dtype=x.dtype, device=x.device)
+    elif out.shape != x.shape or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError("out must be a contiguous tensor of x's shape and dtype")
+    rc = _lib.lib().ir_freeu_fourier_filter(code, B * Cc, H, W, x.data_ptr(), x.stride(1), out.data_ptr(), H * W,
+                                            int(threshold), float(scale), _stream())
+    _lib.check(rc, "ir_freeu_fourier_filter")
+    return out
+
+
+def lanczos_coeffs(in_size: int, out_size: int):
+    """Pillow's LANCZOS tap tables for one axis, computed on the host by the library
+    (``ir_lanczos_coeffs``): ``(bounds (out, 2) int32, kk (out, ksize) int32)`` CPU tensors."""
+    L = _lib.lib()
+    ksize = L.ir_lanczos_ksize(int(in_size), int(out_size))
+    if ksize <= 0:
+        _lib.check(ksize, "ir_lanczos_ksize")
+    bounds = torch.empty((out_size, 2), dtype=torch.int32)
+    kk = torch.empty((out_size, ksize), dtype=torch.int32)
+    _lib.check(L.ir_lanczos_coeffs(int(in_size), int(out_size), bounds.data_ptr(), kk.data_ptr()), "ir_lanczos_coeffs")
+    return bounds, kk
+
+
+def preprocess_lanczos(descs, size: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """Launch ``ir_preprocess_lanczos_u8`` over a ctypes array of ``_lib.ImageDesc`` (built by
+    ``instantrestore_amd.preprocess``); returns ``(n, 3, size, size)`` in ``dtype``."""
+    code = _ANY_DT.get(dtype)
+    if code is None:
+        raise TypeError(f"preprocess: unsupported output dtype {dtype}")
+    n = len(descs)
+    with torch.cuda.device(device):
+        out = torch.empty((n, 3, size, size), dtype=dtype, device=device)
+        rc = _lib.lib().ir_preprocess_lanczos_u8(descs, n, int(size), code, out.data_ptr(), _stream())
+    _lib.check(rc, "ir_preprocess_lanczos_u8")
+    return out
+
+
 def set_attn_variant(variant: int) -> int:
     """tuning hook for benchmarks/tests (0 = auto, 1 = 8-wave, 2 = 4-wave workgroups)"""
     return _lib.lib().ir_set_attn_variant(int(variant))

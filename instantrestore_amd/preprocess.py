@@ -1,0 +1,90 @@
+"""The caller's input transform on the device.
+
+``face_replace/inference/test.py:54-59`` builds, and ``:76,:127,:150`` apply per image on the CPU::
+
+    transforms.Resize(512, interpolation=LANCZOS) -> CenterCrop(512) -> ToTensor() -> Normalize(.5, .5)
+
+:class:`LanczosPreprocessor` does the same for a whole batch of differently sized ``uint8`` RGB
+images that already sit in HBM (decoded upstream, or uploaded raw: H*W*3 bytes instead of a
+float tensor), in two launches: Pillow's 8-bit horizontal pass over the crop's columns, then the
+vertical pass fused with ``/255``, ``(x-0.5)/0.5``, HWC->CHW and the cast.  The resampled bytes are
+bit-identical to ``PIL.Image.resize`` (pillow==10.4.0 algorithm); sizes and crop offsets follow
+torchvision==0.15.2.  Host work is the tap tables only (``ir_lanczos_coeffs``, cached per
+``(in_size, out_size)`` and kept on the device).  No CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from . import ops as _ops
+
+
+def resize_output_size(in_h: int, in_w: int, size: int) -> Tuple[int, int]:
+    """torchvision ``Resize(int)``: short edge -> ``size``, long edge ``int(size * long / short)``."""
+    short, long = (in_w, in_h) if in_w <= in_h else (in_h, in_w)
+    new_long = int(size * long / short)
+    return (new_long, size) if in_w <= in_h else (size, new_long)   # (out_h, out_w)
+
+
+def center_crop_offsets(h: int, w: int, size: int) -> Tuple[int, int]:
+    """torchvision ``CenterCrop``: ``int(round((h - size) / 2.0))`` (round-half-to-even)."""
+    return int(round((h - size) / 2.0)), int(round((w - size) / 2.0))
+
+
+class LanczosPreprocessor:
+    """``pre = LanczosPreprocessor(512, torch.float16); batch = pre(list_of_uint8_HWC_cuda_tensors)``"""
+
+    def __init__(self, size: int = 512, dtype: torch.dtype = torch.float16):
+        self.size, self.dtype = int(size), dtype
+        self._tables: Dict[Tuple[int, int, torch.device], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+        self._tmp: Dict[torch.device, torch.Tensor] = {}
+
+    def _axis(self, n_in: int, n_out: int, device: torch.device):
+        key = (n_in, n_out, device)
+        hit = self._tables.get(key)
+        if hit is None:
+            bounds, kk = _ops.lanczos_coeffs(n_in, n_out)
+            hit = (bounds, bounds.to(device), kk.to(device))   # host bounds: row range of the crop
+            self._tables[key] = hit
+        return hit
+
+    def __call__(self, images: Sequence[torch.Tensor]) -> torch.Tensor:
+        if len(images) == 0:
+            raise ValueError("empty batch")
+        device = images[0].device
+        size = self.size
+        plans, tmp_bytes = [], 0
+        for im in images:
+            if not im.is_cuda:
+                raise RuntimeError("LanczosPreprocessor runs on the MI355X only; got a CPU tensor (no CPU fallback)")
+            if im.device != device:
+                raise RuntimeError("all images must be on one device")
+            if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or im.stride(2) != 1 or im.stride(1) != 3:
+                raise ValueError("images must be uint8 (H, W, 3) with packed RGB pixels")
+            in_h, in_w = int(im.shape[0]), int(im.shape[1])
+            out_h, out_w = resize_output_size(in_h, in_w, size)
+            top, left = center_crop_offsets(out_h, out_w, size)
+            bh_host, bh, kh = self._axis(in_w, out_w, device)
+            bv_host, bv, kv = self._axis(in_h, out_h, device)
+            rows = bv_host[top:top + size]
+            row_first = int(rows[:, 0].min())
+            row_count = int((rows[:, 0] + rows[:, 1]).max()) - row_first
+            plans.append((im, in_h, in_w, out_h, out_w, top, left, bh, kh, bv, kv, row_first, row_count, tmp_bytes))
+            tmp_bytes += (row_count * size * 3 + 255) // 256 * 256
+        tmp = self._tmp.get(device)
+        if tmp is None or tmp.numel() < tmp_bytes:
+            tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=device)
+            self._tmp[device] = tmp
+        descs = (_lib.ImageDesc * len(plans))()
+        for d, (im, in_h, in_w, out_h, out_w, top, left, bh, kh, bv, kv, row_first, row_count, off) in zip(descs, plans):
+            d.src, d.src_row_bytes = im.data_ptr(), im.stride(0)
+            d.in_h, d.in_w, d.out_h, d.out_w = in_h, in_w, out_h, out_w
+            d.crop_top, d.crop_left = top, left
+            d.bounds_h, d.kk_h, d.bounds_v, d.kk_v = bh.data_ptr(), kh.data_ptr(), bv.data_ptr(), kv.data_ptr()
+            d.ksize_h, d.ksize_v = kh.shape[1], kv.shape[1]
+            d.row_first, d.row_count = row_first, row_count
+            d.tmp = tmp.data_ptr() + off
+        return _ops.preprocess_lanczos(descs, size, self.dtype, device)

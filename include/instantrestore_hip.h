@@ -216,12 +216,13 @@ typedef struct ir_image_desc {
   int32_t out_h, out_w;     /* resized size (before the crop) */
   int32_t crop_top, crop_left;
   const int32_t* bounds_h;  /* (out_w, 2) */
-  const int32_t* kk_h;      /* (out_w, ksize_h) */
+  const int32_t* kk_h;      /* (ksize_h, out_w): TAP-MAJOR, the transpose of ir_lanczos_coeffs' table */
   const int32_t* bounds_v;  /* (out_h, 2) */
   const int32_t* kk_v;      /* (out_h, ksize_v) */
   int32_t ksize_h, ksize_v;
   int32_t row_first, row_count; /* source rows touched by the vertical taps of the crop's rows */
-  void* tmp;                /* >= row_count * size * 3 bytes of scratch for this image */
+  int32_t col_first, col_count; /* source columns touched by the horizontal taps of the crop's columns */
+  void* tmp;                /* 4-byte aligned scratch, >= row_count * ((size*3 + 3) & ~3) bytes */
 } ir_image_desc;
 
 int ir_lanczos_ksize(int32_t in_size, int32_t out_size);            /* taps per output sample; < 0 on error */

@@ -40,7 +40,8 @@ class ImageDesc(C.Structure):
 
     _fields_ = [("src", vp), ("src_row_bytes", i64), ("in_h", i32), ("in_w", i32), ("out_h", i32), ("out_w", i32),
                 ("crop_top", i32), ("crop_left", i32), ("bounds_h", vp), ("kk_h", vp), ("bounds_v", vp), ("kk_v", vp),
-                ("ksize_h", i32), ("ksize_v", i32), ("row_first", i32), ("row_count", i32), ("tmp", vp)]
+                ("ksize_h", i32), ("ksize_v", i32), ("row_first", i32), ("row_count", i32),
+                ("col_first", i32), ("col_count", i32), ("tmp", vp)]
 
 
 # name -> (restype, argtypes); every symbol include/instantrestore_hip.h declares

@@ -275,6 +275,10 @@ int ir_preprocess_lanczos_u8(const ir_image_desc* images, int32_t n_images, int3
                   d.crop_top, d.crop_left, d.out_h, d.out_w);
     if (d.ksize_h <= 0 || d.ksize_v <= 0 || d.row_first < 0 || d.row_count <= 0 || d.row_first + d.row_count > d.in_h)
       return fail(IR_ERR_INVALID_ARG, "image %d: bad tap tables / row range", i);
+    if (d.col_first < 0 || d.col_count <= 0 || d.col_first + d.col_count > d.in_w)
+      return fail(IR_ERR_INVALID_ARG, "image %d: bad column range", i);
+    if ((int64_t)d.col_count * 3 > 15000) return fail(IR_ERR_UNSUPPORTED, "image %d: more than 5000 source columns under the crop", i);
+    if (reinterpret_cast<uintptr_t>(d.tmp) & 3u) return fail(IR_ERR_UNSUPPORTED, "image %d: tmp must be 4-byte aligned", i);
   }
   for (int first = 0; first < n_images; first += kPreprocessImagesPerLaunch) {
     PreprocessKParams p;
@@ -282,7 +286,8 @@ int ir_preprocess_lanczos_u8(const ir_image_desc* images, int32_t n_images, int3
     p.n = n_images - first < kPreprocessImagesPerLaunch ? n_images - first : kPreprocessImagesPerLaunch;
     p.size = size;
     p.first_image = first;
-    int max_rows = 0;
+    p.tmp_pitch = (size * 3 + 3) & ~3;
+    int max_rows = 0, max_span = 0, max_ksv = 0;
     for (int i = 0; i < p.n; ++i) {
       const ir_image_desc& d = images[first + i];
       ResampleImageK& k = p.img[i];
@@ -290,10 +295,12 @@ int ir_preprocess_lanczos_u8(const ir_image_desc* images, int32_t n_images, int3
       k.bounds_h = d.bounds_h; k.kk_h = d.kk_h; k.bounds_v = d.bounds_v; k.kk_v = d.kk_v;
       k.tmp = (unsigned char*)d.tmp; k.ksize_h = d.ksize_h; k.ksize_v = d.ksize_v;
       k.crop_top = d.crop_top; k.crop_left = d.crop_left; k.row_first = d.row_first; k.row_count = d.row_count;
+      k.col_first = d.col_first; k.col_count = d.col_count; k.in_h = d.in_h; k.in_w = d.in_w; k.out_w = d.out_w;
       if (d.row_count > max_rows) max_rows = d.row_count;
+      if (d.col_count * 3 > max_span) max_span = d.col_count * 3;
+      if (d.ksize_v > max_ksv) max_ksv = d.ksize_v;
     }
-    if (max_rows > 65535) return fail(IR_ERR_UNSUPPORTED, "more than 65535 source rows under one crop");
-    const hipError_t e = ir_launch_preprocess(p, max_rows, out_dtype, out, (hipStream_t)stream);
+    const hipError_t e = ir_launch_preprocess(p, max_rows, max_span, max_ksv, out_dtype, out, (hipStream_t)stream);
     if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "preprocess launch: %s", hipGetErrorString(e));
   }
   return IR_OK;

@@ -100,20 +100,23 @@ struct ResampleImageK {
   const unsigned char* src;   // (in_h, in_w, 3) uint8, pixel stride 3 bytes
   int64_t src_row_bytes;
   const int32_t* bounds_h;    // (out_w, 2): first source column, tap count
-  const int32_t* kk_h;        // (out_w, ksize_h) 22-bit fixed-point taps
+  const int32_t* kk_h;        // (ksize_h, out_w) 22-bit fixed-point taps, TRANSPOSED (tap-major)
   const int32_t* bounds_v;    // (out_h, 2)
   const int32_t* kk_v;        // (out_h, ksize_v)
   unsigned char* tmp;         // (row_count, size, 3): horizontal pass of the crop's columns
   int32_t ksize_h, ksize_v;
   int32_t crop_top, crop_left;
   int32_t row_first, row_count;  // source rows the crop's vertical taps touch
+  int32_t col_first, col_count;  // source columns the crop's horizontal taps touch
+  int32_t in_h, in_w, out_w;
 };
 constexpr int kPreprocessImagesPerLaunch = 16;
 struct PreprocessKParams {
   ResampleImageK img[kPreprocessImagesPerLaunch];
-  int32_t n, size, first_image;
+  int32_t n, size, first_image, tmp_pitch;  // tmp rows are tmp_pitch bytes apart (multiple of 4)
 };
-hipError_t ir_launch_preprocess(const PreprocessKParams& p, int max_rows, int dtype, void* out, hipStream_t s);
+hipError_t ir_launch_preprocess(const PreprocessKParams& p, int max_rows, int max_span_bytes, int max_ksize_v, int dtype,
+                                void* out, hipStream_t s);
 hipError_t ir_launch_freeu_fourier(const void* x, void* out, int dtype, int64_t planes, int H, int W, int64_t sp_in,
                                    int64_t sp_out, int thr, float scale, hipStream_t s);
 int ir_host_lanczos_ksize(int in_size, int out_size);

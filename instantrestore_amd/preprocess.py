@@ -14,7 +14,8 @@ torchvision==0.15.2.  Host work is the tap tables only (``ir_lanczos_coeffs``, c
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
+import ctypes as C
+from typing import Dict, Sequence, Tuple
 
 import torch
 
@@ -39,7 +40,9 @@ class LanczosPreprocessor:
 
     def __init__(self, size: int = 512, dtype: torch.dtype = torch.float16):
         self.size, self.dtype = int(size), dtype
-        self._tables: Dict[Tuple[int, int, torch.device], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = {}
+        self._pitch = (self.size * 3 + 3) // 4 * 4
+        self._tables: Dict[Tuple[int, int, torch.device], Tuple[torch.Tensor, ...]] = {}
+        self._plans: Dict[Tuple[int, int, torch.device], Tuple[_lib.ImageDesc, int]] = {}
         self._tmp: Dict[torch.device, torch.Tensor] = {}
 
     def _axis(self, n_in: int, n_out: int, device: torch.device):
@@ -47,44 +50,66 @@ class LanczosPreprocessor:
         hit = self._tables.get(key)
         if hit is None:
             bounds, kk = _ops.lanczos_coeffs(n_in, n_out)
-            hit = (bounds, bounds.to(device), kk.to(device))   # host bounds: row range of the crop
+            # host bounds: row / column range of the crop; device taps in both layouts (the
+            # horizontal pass reads them tap-major so neighbouring lanes read neighbouring ints)
+            hit = (bounds, bounds.to(device), kk.to(device), kk.t().contiguous().to(device))
             self._tables[key] = hit
         return hit
 
-    def __call__(self, images: Sequence[torch.Tensor]) -> torch.Tensor:
+    def _plan(self, in_h: int, in_w: int, device: torch.device):
+        """everything about one source size that does not depend on the pixels: a prototype
+        descriptor (sizes, crop, table pointers, row/column ranges) and its scratch bytes"""
+        key = (in_h, in_w, device)
+        hit = self._plans.get(key)
+        if hit is None:
+            size = self.size
+            out_h, out_w = resize_output_size(in_h, in_w, size)
+            top, left = center_crop_offsets(out_h, out_w, size)
+            bh_host, bh, _, kh_t = self._axis(in_w, out_w, device)
+            bv_host, bv, kv, _ = self._axis(in_h, out_h, device)
+            rows, cols = bv_host[top:top + size], bh_host[left:left + size]
+            d = _lib.ImageDesc()
+            d.in_h, d.in_w, d.out_h, d.out_w = in_h, in_w, out_h, out_w
+            d.crop_top, d.crop_left = top, left
+            d.bounds_h, d.kk_h, d.bounds_v, d.kk_v = bh.data_ptr(), kh_t.data_ptr(), bv.data_ptr(), kv.data_ptr()
+            d.ksize_h, d.ksize_v = kh_t.shape[0], kv.shape[1]
+            d.row_first, d.col_first = int(rows[:, 0].min()), int(cols[:, 0].min())
+            d.row_count = int((rows[:, 0] + rows[:, 1]).max()) - d.row_first
+            d.col_count = int((cols[:, 0] + cols[:, 1]).max()) - d.col_first
+            hit = (d, (d.row_count * self._pitch + 255) // 256 * 256)
+            self._plans[key] = hit
+        return hit
+
+    def prepare(self, images: Sequence[torch.Tensor]):
+        """descriptor array for a batch (host work only: no launch)"""
         if len(images) == 0:
             raise ValueError("empty batch")
         device = images[0].device
-        size = self.size
-        plans, tmp_bytes = [], 0
-        for im in images:
+        descs = (_lib.ImageDesc * len(images))()
+        offsets, tmp_bytes = [], 0
+        for i, im in enumerate(images):
             if not im.is_cuda:
                 raise RuntimeError("LanczosPreprocessor runs on the MI355X only; got a CPU tensor (no CPU fallback)")
             if im.device != device:
                 raise RuntimeError("all images must be on one device")
             if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or im.stride(2) != 1 or im.stride(1) != 3:
                 raise ValueError("images must be uint8 (H, W, 3) with packed RGB pixels")
-            in_h, in_w = int(im.shape[0]), int(im.shape[1])
-            out_h, out_w = resize_output_size(in_h, in_w, size)
-            top, left = center_crop_offsets(out_h, out_w, size)
-            bh_host, bh, kh = self._axis(in_w, out_w, device)
-            bv_host, bv, kv = self._axis(in_h, out_h, device)
-            rows = bv_host[top:top + size]
-            row_first = int(rows[:, 0].min())
-            row_count = int((rows[:, 0] + rows[:, 1]).max()) - row_first
-            plans.append((im, in_h, in_w, out_h, out_w, top, left, bh, kh, bv, kv, row_first, row_count, tmp_bytes))
-            tmp_bytes += (row_count * size * 3 + 255) // 256 * 256
+            proto, nbytes = self._plan(int(im.shape[0]), int(im.shape[1]), device)
+            C.memmove(C.byref(descs[i]), C.byref(proto), C.sizeof(_lib.ImageDesc))
+            descs[i].src, descs[i].src_row_bytes = im.data_ptr(), im.stride(0)
+            offsets.append(tmp_bytes)
+            tmp_bytes += nbytes
         tmp = self._tmp.get(device)
         if tmp is None or tmp.numel() < tmp_bytes:
             tmp = torch.empty(tmp_bytes, dtype=torch.uint8, device=device)
             self._tmp[device] = tmp
-        descs = (_lib.ImageDesc * len(plans))()
-        for d, (im, in_h, in_w, out_h, out_w, top, left, bh, kh, bv, kv, row_first, row_count, off) in zip(descs, plans):
-            d.src, d.src_row_bytes = im.data_ptr(), im.stride(0)
-            d.in_h, d.in_w, d.out_h, d.out_w = in_h, in_w, out_h, out_w
-            d.crop_top, d.crop_left = top, left
-            d.bounds_h, d.kk_h, d.bounds_v, d.kk_v = bh.data_ptr(), kh.data_ptr(), bv.data_ptr(), kv.data_ptr()
-            d.ksize_h, d.ksize_v = kh.shape[1], kv.shape[1]
-            d.row_first, d.row_count = row_first, row_count
-            d.tmp = tmp.data_ptr() + off
-        return _ops.preprocess_lanczos(descs, size, self.dtype, device)
+        base = tmp.data_ptr()
+        for i, off in enumerate(offsets):
+            descs[i].tmp = base + off
+        return descs, device
+
+    def run(self, descs, device) -> torch.Tensor:
+        return _ops.preprocess_lanczos(descs, self.size, self.dtype, device)
+
+    def __call__(self, images: Sequence[torch.Tensor]) -> torch.Tensor:
+        return self.run(*self.prepare(images))

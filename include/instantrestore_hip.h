@@ -246,6 +246,20 @@ int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32
                             int64_t x_plane_stride, void* out, int64_t out_plane_stride, int32_t threshold,
                             float scale, void* stream);
 
+/*
+ * ir_linear_fwd - y = x W^T (+ bias) for the q/k/v (fused, N = 3C) and out projections of the
+ * 64x64-token layer class.
+ *
+ * Replaces attn.to_q/to_k/to_v and attn.to_out[0] (nn.Linear; attn_processors.py:222-230,267) for
+ * in_features K in {64, 128, ..., 320}: X-stationary MFMA kernel, W streamed through LDS, fp32
+ * accumulation, one rounding to the 16-bit dtype (bias added in fp32 before it).  Other K return
+ * IR_ERR_UNSUPPORTED and the caller keeps the vendor GEMM.
+ *   x (M, K) rows x_ld elements apart; w (N, K) rows w_ld apart (torch Linear weight layout);
+ *   bias (N) or NULL; y (M, N) rows y_ld apart; N % 32 == 0; all ld % 8 == 0, pointers 16-B aligned
+ */
+int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                  int64_t w_ld, const void* bias, void* y, int64_t y_ld, void* stream);
+
 /* library identity / diagnostics */
 int ir_abi_version(void);                  /* == IR_ABI_VERSION */
 const char* ir_build_info(void);           /* "gfx950 hipcc ... <date>" */

@@ -101,6 +101,19 @@ def _autocast_or(weight: torch.Tensor, x: torch.Tensor) -> torch.dtype:
     return weight.dtype
 
 
+_SKINNY_MIN_WORK = 1 << 24   # rows * out_features below which the vendor GEMM is as fast (tools/gpu_gemm_probe.py)
+
+
+def _linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """``F.linear`` with the K <= 320 shapes of the 64x64-token layer class routed to the
+    X-stationary HIP GEMM (``ir_linear_fwd``, 1.5x the vendor kernel there); every other shape is a
+    plain library GEMM and stays one."""
+    rows = x.numel() // x.shape[-1]
+    if rows * w.shape[0] >= _SKINNY_MIN_WORK and _ops.linear_supported(x, w, bias):
+        return _ops.linear(x, w, bias)
+    return torch.nn.functional.linear(x, w, bias)
+
+
 def _project_qkv(attn, st: _Prepared):
     """``to_q`` / ``to_k`` / ``to_v`` of the reference (attn_processors.py:222-230).
 
@@ -124,16 +137,16 @@ def _project_qkv(attn, st: _Prepared):
     dtype = _autocast_or(effs[0][0].weight, st.hidden)
     w = _lora.cached_weight(attn, "_ir_qkv_cache", (tq, tk, tv), dtype)
     x = st.hidden if st.hidden.dtype == dtype else st.hidden.to(dtype)
-    qkv = torch.nn.functional.linear(x, w)
+    qkv = _linear(x, w, None)
     c = w.shape[0] // 3
     return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
 
 
 def _project_out(attn, tokens: torch.Tensor) -> torch.Tensor:
     """``to_out[0]`` (attn_processors.py:267): one GEMM also when the module is a LoRA wrapper in
-    inference state; the module call itself otherwise (plain ``nn.Linear`` included)."""
+    inference state; the module call itself in training or when it cannot be folded."""
     proj = attn.to_out[0]
-    if type(proj) is nn.Linear or torch.is_grad_enabled():
+    if torch.is_grad_enabled():
         return proj(tokens)
     eff = _lora.effective_linear(proj)
     if eff is None:
@@ -141,8 +154,10 @@ def _project_out(attn, tokens: torch.Tensor) -> torch.Tensor:
     dtype = _autocast_or(eff[0].weight, tokens)
     w = _lora.cached_weight(attn, "_ir_out_cache", (proj,), dtype)
     bias = eff[0].bias
+    if bias is not None and bias.dtype != dtype:
+        bias = _lora.cached_cast(attn, "_ir_out_bias_cache", bias, dtype)
     x = tokens if tokens.dtype == dtype else tokens.to(dtype)
-    return torch.nn.functional.linear(x, w, None if bias is None else bias.to(dtype))
+    return _linear(x, w, bias)
 
 
 def _same_16bit(q: torch.Tensor, *others: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:

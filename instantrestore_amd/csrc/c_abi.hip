@@ -324,4 +324,26 @@ int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32
   return IR_OK;
 }
 
+int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                  int64_t w_ld, const void* bias, void* y, int64_t y_ld, void* stream) {
+  if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d: fp16 (0) / bf16 (1)", dtype);
+  if (!x || !w || !y) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  if (m <= 0 || n <= 0 || k <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (k % 64 != 0 || k > 320) return fail(IR_ERR_UNSUPPORTED, "K = %d: this kernel covers K in {64,...,320}", k);
+  if (n % 32 != 0) return fail(IR_ERR_UNSUPPORTED, "N = %d must be a multiple of 32", n);
+  if (bias != nullptr && n > kLinearMaxBiasN) return fail(IR_ERR_UNSUPPORTED, "N = %d with bias: at most %d", n, kLinearMaxBiasN);
+  if (m > 0x7fffffffLL - 256) return fail(IR_ERR_UNSUPPORTED, "M too large");
+  if (x_ld < k || w_ld < k || y_ld < n || (x_ld % 8) || (w_ld % 8) || (y_ld % 8))
+    return fail(IR_ERR_UNSUPPORTED, "leading dimensions must cover a row and be multiples of 8 elements");
+  if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (bias != nullptr && !aligned16(bias)))
+    return fail(IR_ERR_UNSUPPORTED, "pointers must be 16-byte aligned");
+  if ((int64_t)n * w_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "weight larger than 2 GiB");
+  LinearKParams p;
+  p.x = x; p.w = w; p.bias = bias; p.y = y; p.x_ld = x_ld; p.w_ld = w_ld; p.y_ld = y_ld;
+  p.M = (int32_t)m; p.N = n; p.K = k; p.nsplit = 1;
+  const hipError_t e = ir_launch_linear_skinny(p, dtype, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "linear launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
 }  // extern "C"

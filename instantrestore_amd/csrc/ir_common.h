@@ -62,6 +62,7 @@ static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 // 3-input max in one VALU op. Plain fmaxf() chains make hipcc canonicalise every MFMA output
 // first (a v_max_f32 x,x,x per element); the asm form takes the raw registers.

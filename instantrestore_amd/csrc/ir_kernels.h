@@ -120,4 +120,16 @@ hipError_t ir_launch_preprocess(const PreprocessKParams& p, int max_rows, int ma
 hipError_t ir_launch_freeu_fourier(const void* x, void* out, int dtype, int64_t planes, int H, int W, int64_t sp_in,
                                    int64_t sp_out, int thr, float scale, hipStream_t s);
 int ir_host_lanczos_ksize(int in_size, int out_size);
+
+// ---- linear_skinny.hip: Y = X W^T (+ bias) for K <= 320 (X-stationary, W streamed) ---------------
+constexpr int kLinearMaxBiasN = 4096;
+struct LinearKParams {
+  const void* x;     // (M, K) rows x_ld elements apart
+  const void* w;     // (N, K) rows w_ld elements apart (torch Linear weight)
+  const void* bias;  // (N) or nullptr
+  void* y;           // (M, N) rows y_ld elements apart
+  int64_t x_ld, w_ld, y_ld;
+  int32_t M, N, K, nsplit;
+};
+hipError_t ir_launch_linear_skinny(const LinearKParams& p, int dtype, hipStream_t s);
 void ir_host_lanczos_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk);

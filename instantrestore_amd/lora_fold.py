@@ -105,3 +105,13 @@ def cached_weight(owner, slot: str, mods, dtype) -> Optional[torch.Tensor]:
         cache = (key, w.contiguous())
         owner.__dict__[slot] = cache
     return cache[1]
+
+
+def cached_cast(owner, slot: str, t: torch.Tensor, dtype) -> torch.Tensor:
+    """``t.to(dtype)`` cached on ``owner`` (bias under autocast), keyed on identity and version"""
+    key = (t.data_ptr(), t._version, t.device, dtype)
+    cache = owner.__dict__.get(slot)
+    if cache is None or cache[0] != key:
+        cache = (key, t.detach().to(dtype))
+        owner.__dict__[slot] = cache
+    return cache[1]

@@ -313,6 +313,34 @@ def tensor2im_u8(x: torch.Tensor) -> torch.Tensor:
     return out[0] if squeeze else out
 
 
+LINEAR_MAX_K = 320   # ir_linear_fwd: in_features in {64, ..., 320}; everything else is the vendor GEMM's
+
+
+def linear_supported(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
+    """shapes / layouts ``ir_linear_fwd`` implements (the caller keeps ``F.linear`` otherwise)"""
+    n, k = weight.shape
+    return (x.is_cuda and x.dtype in _DT and weight.dtype == x.dtype and x.shape[-1] == k
+            and k % 64 == 0 and k <= LINEAR_MAX_K and n % 32 == 0 and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
+            and (bias is None or (bias.dtype == x.dtype and bias.is_contiguous() and n <= 4096))
+            and x.numel() > 0)
+
+
+@_on_tensor_device
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear(x, weight, bias)`` for 16-bit ``x (..., K)``, ``weight (N, K)`` with K <= 320
+    (``ir_linear_fwd``): fp32 accumulation, one rounding.  Raises for unsupported shapes."""
+    _need_gpu(x, weight, bias)
+    n, k = weight.shape
+    x2 = x.reshape(-1, k)
+    if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
+        x2 = x2.contiguous()
+    y = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
+    rc = _lib.lib().ir_linear_fwd(_dtype_code(x), x2.shape[0], n, k, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
+                                  weight.stride(0), None if bias is None else bias.data_ptr(), y.data_ptr(), n, _stream())
+    _lib.check(rc, "ir_linear_fwd")
+    return y.view(*x.shape[:-1], n)
+
+
 _ANY_DT = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
 
 

@@ -73,3 +73,8 @@ def zero_invalid_refs(k, v, valid_indices, *, heads):
     for b, idx in enumerate(torch.as_tensor(valid_indices).tolist()):
         k[b, int(idx):] = 0
         v[b, int(idx):] = 0
+
+
+def linear_supported(x, weight, bias):
+    """the stand-in has no GEMM of its own: the processors keep ``F.linear`` on CPU"""
+    return False

@@ -1,0 +1,62 @@
+"""GPU parity of ir_linear_fwd (the K <= 320 projection GEMM) against a float64 matmul of the same
+16-bit inputs.  Tolerance (floating point): fp32 accumulation + one rounding to the 16-bit output:
+|err| <= 2^-10 (fp16) / 2^-7 (bf16) relative to max(1, |y|) - half an output ulp plus slack for the
+accumulation order."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("M,N,K,bias", [
+    (256, 32, 64, False), (300, 96, 128, True), (1000, 960, 320, False), (4096, 320, 320, True),
+    (33, 64, 320, True), (1, 32, 64, False), (8192, 960, 320, False), (777, 1920, 256, True), (512, 3840, 192, False),
+])
+def test_linear_matches_float64(dtype, M, N, K, bias):
+    from instantrestore_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g).to(dtype)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(N, generator=g).to(dtype) if bias else None
+    assert ops.linear_supported(x.cuda(), w.cuda(), None if b is None else b.cuda())
+    y = ops.linear(x.cuda(), w.cuda(), None if b is None else b.cuda())
+    assert y.shape == (M, N) and y.dtype == dtype
+    ref = x.double().numpy() @ w.double().numpy().T
+    if bias:
+        ref = ref + b.double().numpy()
+    err = np.abs(y.double().cpu().numpy() - ref)
+    bound = TOL[dtype] * np.maximum(1.0, np.abs(ref))
+    assert (err <= bound).all(), (err.max(), np.unravel_index(np.argmax(err - bound), err.shape))
+
+
+def test_linear_exact_column_order_and_strided_input():
+    """integer-valued inputs make every product exact: any permutation of output columns / rows or a
+    wrong lane-pair exchange shows up as an exact mismatch.  Also batched (B, L, K) input views."""
+    from instantrestore_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-3, 4, (2, 130, 320), generator=g).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (96, 320), generator=g).to(torch.bfloat16)
+    b = torch.randint(-4, 5, (96,), generator=g).to(torch.bfloat16)
+    y = ops.linear(x.cuda(), w.cuda(), b.cuda()).cpu()
+    ref = (x.float() @ w.float().T + b.float())
+    assert y.shape == (2, 130, 96)
+    assert torch.equal(y.float(), ref.to(torch.bfloat16).float())
+    # weight given as a row slice of a bigger (fused) weight: w_ld > K is not needed, but N offset is
+    wbig = torch.randint(-2, 3, (3 * 96, 320), generator=g).to(torch.bfloat16).cuda()
+    y2 = ops.linear(x.cuda(), wbig[96:192]).cpu()
+    assert torch.equal(y2.float(), (x.float() @ wbig[96:192].cpu().float().T).to(torch.bfloat16).float())
+
+
+def test_linear_rejects_what_it_does_not_implement():
+    from instantrestore_amd import _lib, ops
+    x = torch.zeros(64, 640, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(64, 640, device="cuda", dtype=torch.bfloat16)
+    assert not ops.linear_supported(x, w, None)
+    with pytest.raises(_lib.IRError):
+        ops.linear(x, w)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(32, 64, dtype=torch.bfloat16))

@@ -1,0 +1,26 @@
+#!/usr/bin/env bash
+# Generic PMC passes (run on the GPU box via gpurun): counters only, one rocprofv3 run per pass.
+# usage: tools/pmc_kernel.sh <tag> <kernel-name-substring> -- <python script and args>
+set -u
+TAG=$1; KN=$2; shift 3
+R=$PWD; OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS"
+P2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD"
+P3="FETCH_SIZE GRBM_GUI_ACTIVE"
+P4="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
+i=0
+for P in "$P1" "$P2" "$P3" "$P4"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT -o pass$i -- python "$@" > $OUT/pass$i.log 2>&1
+done
+python3 - "$OUT" "$KN" <<'PY'
+import csv, glob, sys, collections
+out, kn = sys.argv[1], sys.argv[2]
+for f in sorted(glob.glob(out + "/*counter_collection.csv")):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if kn in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    print(f.split("/")[-1], {k: round(sum(v) / len(v), 1) for k, v in agg.items()}, "n=%d" % max(len(v) for v in agg.values()) if agg else "")
+PY

@@ -97,6 +97,11 @@ def lib() -> C.CDLL:
         got = handle.ir_abi_version()
         if got != ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}; rebuild")
+        # IR_ATTN_VARIANT=<n>: process-wide kernel variant without touching code (ir_set_attn_variant); e.g.
+        # 11 = "prescaled Q" fast mode (+6 % attention throughput, one extra 16-bit rounding of Q)
+        var = os.environ.get("IR_ATTN_VARIANT")
+        if var:
+            handle.ir_set_attn_variant(int(var))
         _lib = handle
     return _lib
 

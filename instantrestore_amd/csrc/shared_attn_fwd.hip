@@ -443,6 +443,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   if (base == 7) return ir_launch_shared_attn_fwd_pipe(p, dtype, 7, s);  // same, DMA issued from asm
   if (base == 9) return ir_launch_shared_attn_fwd_pipe(p, dtype, 9, s);  // straight schedule + asm DMA, 3 waves/SIMD
   if (base == 10) return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);  // default + lazy max (deferred rescale)
+  if (base == 11) return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);  // + pre-scaled Q, reference through the MFMA C operand
   if (base == 12 && p.aa == nullptr) return ir_launch_shared_attn_fwd_w64(p, dtype, s);  // 64 rows per wave (no fold)
   if (base == 12) return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);
   if (base == 8) return ir_launch_shared_attn_fwd_pp(p, dtype, s);  // ping-pong wave groups (shared_attn_fwd_pp.hip)

@@ -82,6 +82,15 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const v8*)(qp + ks * 16);
   }
+  // PRESC: Q carries scale*log2(e) (one more rounding of Q to the 16-bit type), so the scores leave the
+  // matrix pipe already in the exp2 domain and - with the running reference fed through the C operand
+  // of the first QK^T MFMA - already shifted: no per-score scale-and-subtract on the VALU.
+  constexpr bool PRESC = (ABL & 2048) != 0;
+  if (PRESC) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[ks] = __builtin_convertvector(__builtin_convertvector(qf[ks], f32x8) * p.scale_log2, v8);
+  }
 
   // ---- staging coordinates -------------------------------------------------------------------
   const int slot = tid & 7;
@@ -199,9 +208,12 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
   f32x2 la = {0.f, 0.f}, lb = {0.f, 0.f};  // this lane's partial row sums of the current segment
   float l_tot = 0.f;                        // FOLD: folded row sum, relative to m_ot
   float m_ot = -INFINITY;                   // FOLD: the running max the LDS total is scaled to
-  float m_run = -INFINITY;
+  float m_run = PRESC ? 0.f : -INFINITY;    // PRESC: the reference lives in the exp2 domain and starts at 0
   const float c2 = p.scale_log2;
-  const float lazy_thr = 6.0f / c2;  // LAZYMAX: raw-score growth that forces a rescale
+  const float lazy_thr = PRESC ? 6.0f : 6.0f / c2;  // LAZYMAX: score growth that forces a rescale
+  f32x16 mneg;                              // PRESC: -m_run in every register: C operand of the first QK^T MFMA
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mneg[r] = 0.f;
   const int NTILES = tile_end - tile_begin;  // tiles of THIS piece (all of them when not split)
 
   // PV/softmax stream position (the QK^T of tile t+1 is issued unmasked; masking happens when a
@@ -228,6 +240,16 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     }
   };
   auto qk_mfma = [&](f32x16& s0, f32x16& s1, const v8 (&kf0)[4], const v8 (&kf1)[4]) {
+    if (PRESC) {
+      s0 = Tr::mfma(kf0[0], qf[0], mneg);
+      s1 = Tr::mfma(kf1[0], qf[0], mneg);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) {
+        s0 = Tr::mfma(kf0[ks], qf[ks], s0);
+        s1 = Tr::mfma(kf1[ks], qf[ks], s1);
+      }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
@@ -251,7 +273,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lseg), __float_as_uint(lseg), false, false);
       lseg = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
-    const float f = fast_exp2((m_ot - m_run) * c2);  // m_ot = -inf the first time: f = 0
+    const float f = fast_exp2(PRESC ? (m_ot - m_run) : (m_ot - m_run) * c2);  // m_ot = -inf the first time: f = 0
     l_tot = l_tot * f + lseg;
     m_ot = m_run;
     const bool is_ref = !(p.include_self && cseg == 0);
@@ -316,11 +338,27 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
       mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), mx);
     }
+    if (PRESC) {
+      // S(t) is already c2*s - m_run.  First tile of the piece: adopt its row max whatever its sign (the
+      // reference started at 0); later tiles: move only when some row grew by more than 2^6 (lazy).
+      if (t == 0 || __any(mx > lazy_thr)) {
+        const float d = t == 0 ? mx : (mx > 0.f ? mx : 0.f);
+        const float alpha = t == 0 ? 1.f : fast_exp2(-d);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; c0[r] -= d; c1[r] -= d; }
+        la *= alpha;
+        lb *= alpha;
+        m_run += d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mneg[r] = -m_run;
+      }
+    }
     const float m_new = max3(m_run, mx, mx);
     // (3) rescale only when some row's max moved (exact).  LAZYMAX (experiment): keep the old
     // reference while no row's max grew by more than 2^6 in the exp2 domain, so P <= 64.
     constexpr bool LAZYMAX = (ABL & 1024) != 0;
-    if (LAZYMAX ? __any(mx > m_run + lazy_thr) : __any(m_new != m_run)) {
+    if (PRESC) {
+    } else if (LAZYMAX ? __any(mx > m_run + lazy_thr) : __any(m_new != m_run)) {
       const float alpha = fast_exp2((m_run - m_new) * c2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
@@ -343,8 +381,10 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     for (int r = 0; r < 16; r += 2) {
       f32x2 t0v = {c0[r], c0[r + 1]};
       f32x2 t1v = {c1[r], c1[r + 1]};
-      t0v = __builtin_elementwise_fma(t0v, cc, nm);
-      t1v = __builtin_elementwise_fma(t1v, cc, nm);
+      if (!PRESC) {
+        t0v = __builtin_elementwise_fma(t0v, cc, nm);
+        t1v = __builtin_elementwise_fma(t1v, cc, nm);
+      }
       t0v[0] = fast_exp2(t0v[0]); t0v[1] = fast_exp2(t0v[1]);
       t1v[0] = fast_exp2(t1v[0]); t1v[1] = fast_exp2(t1v[1]);
       la += t0v;
@@ -484,7 +524,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
       *(f32x4*)(wo + 32 + 8 * g4 + 4 * hi) = x1;
     }
     if (hi == 0) {
-      p.ws_ml[prow * 2] = m_run;
+      p.ws_ml[prow * 2] = PRESC ? m_run / c2 : m_run;   // the combine kernel weighs pieces by raw-score maxima
       p.ws_ml[prow * 2 + 1] = l_fin;
     }
     return;
@@ -505,7 +545,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
       *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
     }
     if (p.lse != nullptr && hi == 0)
-      p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_run * p.scale + __logf(l_fin);
+      p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = (PRESC ? m_run * 0.69314718f : m_run * p.scale) + __logf(l_fin);
   }
 }
 
@@ -597,6 +637,7 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   if (nw == 6) return fold ? launch<T, 4, true, 64>(p, s) : launch<T, 4, false, 64>(p, s);  // LDS-DMA staging
   if (nw == 7) return fold ? launch<T, 4, true, 128>(p, s) : launch<T, 4, false, 128>(p, s);  // LDS-DMA from asm
   if (nw == 10) return fold ? launch<T, 4, true, 128 | 1024>(p, s) : launch<T, 4, false, 128 | 1024>(p, s);  // asm DMA + lazy max
+  if (nw == 11) return fold ? launch<T, 4, true, 128 | 1024 | 2048>(p, s) : launch<T, 4, false, 128 | 1024 | 2048>(p, s);  // + pre-scaled Q, reference through the C operand
   if (nw == 9) return fold ? launch<T, 4, true, 256>(p, s) : launch<T, 4, false, 256>(p, s);  // straight schedule, 3 waves/SIMD
   return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
 }

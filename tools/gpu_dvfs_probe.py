@@ -13,8 +13,9 @@ for name, fill in (("random", None), ("zeros", 0.0), ("const", 0.37), ("random a
     else:
         q, k, v = (torch.full((B, L, C), fill, device="cuda", dtype=dt) for _ in range(3))
         rk = torch.full((B, N, L, C), fill, device="cuda", dtype=dt); rv = rk.clone()
-    for var in (0, 12):
+    for var in (10, 11, 10, 11):
         ops.set_attn_variant(var)
-        ops.time_shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, iters=3)
-        ms = min(ops.time_shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, iters=10) for _ in range(3))
+        aff = ops.adain_stats(v, rv, heads=H)
+        ops.time_shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, iters=3, adain=aff)
+        ms = min(ops.time_shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, iters=10, adain=aff) for _ in range(3))
         print(f"{name:13s} v{var}: {ms:.4f} ms {attn_flops(B, L, 5*L, C)/ms/1e9:7.1f} TF/s")

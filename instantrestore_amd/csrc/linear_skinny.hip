@@ -102,17 +102,18 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   // stored there too (same bytes), which keeps the number of stores per iteration constant - the
   // s_waitcnt arithmetic of the main loop counts them
   const int row0 = mb * 256 + wid * 64;
+  auto store_part = [&](int j, int n0) {   // 16 rows x 64 B: one of the four stores of a finished chunk
+    const int r = 16 * j + (lane >> 2);
+    const u32x4 v = *(const u32x4*)(tb + r * TPITCH + (lane & 3) * 16);
+    const int row = row0 + r;
+    T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 3) * 8;
+    *(u32x4*)yp = v;
+  };
   auto store_chunk = [&](const f32x16& a, const f32x16& b, int n0) {
     stage_block(a, 0, n0);
     stage_block(b, 32, n0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = 16 * j + (lane >> 2);
-      const u32x4 v = *(const u32x4*)(tb + r * TPITCH + (lane & 3) * 16);
-      const int row = row0 + r;
-      T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 3) * 8;
-      *(u32x4*)yp = v;
-    }
+    for (int j = 0; j < 4; ++j) store_part(j, n0);
   };
 
   // Iteration i: start the transfer of chunk i+1, send chunk i-1's results on their way, compute chunk i,
@@ -122,7 +123,13 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   for (int i = 0; i < ncl; ++i) {
     const int c = c_begin + i, cur = i & 1;
     if (i + 1 < ncl) issue_chunk(c + 1, cur ^ 1);   // its slot was last read in iteration i-1
-    if (i > 0) store_chunk(accA, accB, (c - 1) * NCH);
+    // chunk i-1 leaves in four 16-row stores that are issued BETWEEN the MFMA groups of chunk i: a write
+    // path running at HBM speed back-pressures the issuing wave, and four stores in a row stall it (and
+    // its lockstep partner workgroup) while the matrix pipe idles
+    if (i > 0) {
+      stage_block(accA, 0, (c - 1) * NCH);
+      stage_block(accB, 32, (c - 1) * NCH);
+    }
     const unsigned char* Wb = smem + cur * CHUNK_BYTES;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
@@ -143,6 +150,14 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
       for (int ks = 0; ks < 4; ++ks) {
         accA = Tr::mfma(wf[s & 1][ks], xA[4 * s + ks], accA);
         accB = Tr::mfma(wf[s & 1][ks], xB[4 * s + ks], accB);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i > 0) {   // KS < 4: the remaining parts go out after the last group
+        if (s < 4) store_part(s, (c - 1) * NCH);
+        if (s == KS - 1) {
+#pragma unroll
+          for (int j = KS; j < 4; ++j) store_part(j, (c - 1) * NCH);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }

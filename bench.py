@@ -114,13 +114,14 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         ops.time_shared_attention(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input, adain=aff, iters=3)
         ms = ops.time_shared_attention(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input,
                                        adain=aff, iters=20)
+        kname = ops.shared_attention_kernel_name(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input, adain=aff)
     lkv = (N + int(train_input)) * L
     flops = attn_flops(B, L, lkv, C)
     tf = flops / (ms * 1e-3) / 1e12
     return {
         "bound": "mfma",
-        "kernel": "shared_attn_fwd_pipe_kernel<%s,4 waves,%s> (L=%d, Lkv=%d, H=%d, B=%d)" % (
-            {torch.bfloat16: "bf16", torch.float16: "f16"}[dtype], "AdaIN fold" if use_adain else "no fold", L, lkv, H, B),
+        "kernel": "%s %s (L=%d, Lkv=%d, H=%d, B=%d)" % (
+            kname, {torch.bfloat16: "bf16", torch.float16: "f16"}[dtype], L, lkv, H, B),
         "achieved": round(tf, 2),
         "peak": MFMA_PEAK_TFLOPS_16BIT,
         "unit": "TFLOP/s",
@@ -129,16 +130,16 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
         "algorithmic_mb_per_launch": round(attn_bytes(B, L, lkv, C) / 1e6, 2),
         # HBM bytes per launch from a separate rocprofv3 --pmc pass of this kernel at this shape
-        # (tools/pmc_attn.sh -> profiles/r1_pmc_shared_attn_pipe.txt); FETCH_SIZE doubled per the
+        # (tools/pmc_attn.sh -> profiles/r1_pmc_shared_attn.txt); FETCH_SIZE doubled per the
         # gfx950 correction of MI355X_MICROARCH.md.  null if the profile is not for this shape.
         "traffic": _pmc_traffic_bytes() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
-        "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_shared_attn_pipe.txt)",
+        "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_shared_attn.txt)",
     }
 
 
 def _pmc_traffic_bytes():
     import ast
-    path = os.path.join(REPO, "profiles", "r1_pmc_shared_attn_pipe.txt")
+    path = os.path.join(REPO, "profiles", "r1_pmc_shared_attn.txt")
     try:
         vals = {}
         for line in open(path):

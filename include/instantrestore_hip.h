@@ -111,6 +111,10 @@ typedef struct ir_shared_attn_args {
  */
 size_t ir_shared_attn_workspace_bytes(void);
 
+/* Name of the kernel ir_shared_attn_fwd would launch for these arguments under the current variant
+ * (reporting only: bench.py's roofline block); "" if the arguments are invalid. Static storage. */
+const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args);
+
 int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream);
 
 /*

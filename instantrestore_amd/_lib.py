@@ -52,6 +52,7 @@ SYMBOLS = {
     "ir_set_attn_variant": (C.c_int, [C.c_int]),
     "ir_shared_attn_workspace_bytes": (C.c_size_t, []),
     "ir_shared_attn_fwd": (C.c_int, [C.POINTER(SharedAttnArgs), vp]),
+    "ir_shared_attn_kernel_name": (C.c_char_p, [C.POINTER(SharedAttnArgs)]),
     "ir_time_shared_attn_fwd": (C.c_int, [C.POINTER(SharedAttnArgs), i32, vp, C.POINTER(f32)]),
     "ir_attn_probs": (C.c_int, [C.POINTER(SharedAttnArgs), vp, vp]),
     "ir_adain_stats_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32]),

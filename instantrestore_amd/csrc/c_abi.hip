@@ -90,6 +90,22 @@ const char* ir_last_error_string(void) { return g_err; }
 int ir_set_attn_variant(int variant) { return g_variant.exchange(variant); }
 
 // 8 XCDs x 64 slots pieces of up to 256 rows, 64 fp32 of O + (max, sum) per row
+const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
+  AttnKParams p;
+  if (build_attn_params(args, &p, false) != IR_OK) return "";
+  const int v = g_variant.load() & 15;
+  const bool fold = p.aa != nullptr;
+  switch (v) {
+    case 0: return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave>")
+                                             : (fold ? "shared_attn_fwd_pipe_kernel<4 waves, lazy max, AdaIN fold>" : "shared_attn_fwd_pipe_kernel<4 waves, lazy max>");
+    case 12: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave>";
+    case 11: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q>";
+    case 10: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max>";
+    case 8: return "shared_attn_fwd_pp_kernel";
+    default: return "shared_attn_fwd (tuning variant)";
+  }
+}
+
 size_t ir_shared_attn_workspace_bytes(void) { return (size_t)8 * 64 * 256 * 66 * sizeof(float); }
 
 int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream) {

@@ -86,6 +86,7 @@ hipError_t ir_launch_shared_attn_fwd_pipe(const AttnKParams& p, int dtype, int n
 hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hipStream_t s);
 hipError_t ir_launch_shared_attn_combine(const AttnKParams& p, int dtype, int qb, int rem, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s);
+bool ir_attn_default_is_w64(const AttnKParams& p);   // the default dispatch rule (variant 0)
 hipError_t ir_launch_shared_attn_fwd_pp(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s);

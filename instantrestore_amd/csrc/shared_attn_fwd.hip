@@ -412,6 +412,11 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 //   9 straight schedule + asm DMA at 3 waves/SIMD   12 64 query rows per wave, no fold (shared_attn_fwd_w64.hip)
 // (tried and removed, see DESIGN.md 4.1: hoisted fragment reads, s_setprio, single-statement asm VALU)
 // variant >> 4: ablation bits - only in -DIR_ABLATIONS builds (timing experiments, WRONG results)
+bool ir_attn_default_is_w64(const AttnKParams& p) {
+  const long items256 = (long)p.B * p.H * ((p.Lq + 255) / 256);
+  return p.Lq >= 4096 && items256 >= 256;
+}
+
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
 #ifdef IR_ABLATIONS
   const int abl = variant >> 4;
@@ -430,11 +435,12 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
 #endif
   const int base = variant & 15;
   if (base == 0) {
-    // default: software-pipelined, 4 waves, asm-issued LDS-DMA staging, lazy max; the 64-rows-per-wave
-    // kernel takes over where it measured faster: no AdaIN fold, long query axis, >= 2 full rounds of
-    // 256-row workgroups (the K/V-capture self-attention of the 64x64-token layers: +6 %)
-    const long items256 = (long)p.B * p.H * ((p.Lq + 255) / 256);
-    if (p.aa == nullptr && p.Lq >= 4096 && items256 >= 1024) return ir_launch_shared_attn_fwd_w64(p, dtype, s);
+    // default: the 64-rows-per-wave kernel (AdaIN folded in a ratio frame) on the long query axes of the
+    // 64x64-token class and above, where it measured 5-6 % faster with and without the fold once there is
+    // at least one full round of 256-row workgroups; the software-pipelined 32-row kernel (4 waves, asm-issued
+    // LDS-DMA staging, lazy max, LDS-resident fold totals) everywhere else - short axes leave the wide
+    // kernel's 256-row items too few to fill the chip
+    if (ir_attn_default_is_w64(p)) return ir_launch_shared_attn_fwd_w64(p, dtype, s);
     return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);
   }
   if (base == 3) return ir_launch_shared_attn_fwd_pipe(p, dtype, 4, s);  // software-pipelined, 4 waves, register staging
@@ -444,8 +450,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   if (base == 9) return ir_launch_shared_attn_fwd_pipe(p, dtype, 9, s);  // straight schedule + asm DMA, 3 waves/SIMD
   if (base == 10) return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);  // default + lazy max (deferred rescale)
   if (base == 11) return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);  // + pre-scaled Q, reference through the MFMA C operand
-  if (base == 12 && p.aa == nullptr) return ir_launch_shared_attn_fwd_w64(p, dtype, s);  // 64 rows per wave (no fold)
-  if (base == 12) return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);
+  if (base == 12) return ir_launch_shared_attn_fwd_w64(p, dtype, s);  // 64 rows per wave
   if (base == 8) return ir_launch_shared_attn_fwd_pp(p, dtype, s);  // ping-pong wave groups (shared_attn_fwd_pp.hip)
   const int nw = (base == 1) ? 8 : 4;
   return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);

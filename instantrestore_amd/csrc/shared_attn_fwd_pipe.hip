@@ -552,8 +552,11 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
 // Merge the K/V-range pieces of the remainder items: one workgroup per remainder item, thread =
 // (row, 32-channel half).  out = sum_j w_j O_j / sum_j w_j l_j with w_j = 2^((m_j - M) c).
 template <typename T, int QB>
-__global__ void __launch_bounds__(QB * 2) shared_attn_combine_kernel(const AttnKParams p) {
-  using v8 = typename ElemTraits<T>::v8;
+__global__ void __launch_bounds__(256) shared_attn_combine_kernel(const AttnKParams p) {
+  // grid: (8 * remainder items per XCD, QB / 16); 256 threads = 16 rows x 16 four-channel groups, so a
+  // wave reads four whole 256-byte partial rows per load and thousands of workgroups are in flight
+  // (one workgroup per item left half the CUs idle on a latency-bound kernel)
+  using v4 = typename ElemTraits<T>::v4;
   const int xcd = blockIdx.x & 7, ri = blockIdx.x >> 3;  // ri: remainder item index inside the XCD chunk
   const int rem_x = p.sk_ix - p.sk_full;
   const int item_local = p.sk_full + ri;
@@ -561,37 +564,25 @@ __global__ void __launch_bounds__(QB * 2) shared_attn_combine_kernel(const AttnK
   if (ri >= rem_x || lin >= p.sk_items) return;
   const int bh = lin / p.nqb, qb = lin - bh * p.nqb;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+  const int row = blockIdx.y * 16 + (threadIdx.x >> 4), grp = threadIdx.x & 15;
   const int qrow = qb * QB + row;
   if (qrow >= p.Lq) return;
   const int64_t base = (int64_t)(xcd * rem_x + ri) * p.sk_k;
   float M = -INFINITY;
   for (int j = 0; j < p.sk_k; ++j) M = fmaxf(M, p.ws_ml[((base + j) * QB + row) * 2]);
-  float acc[32];
-#pragma unroll
-  for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float L = 0.f;
   for (int j = 0; j < p.sk_k; ++j) {
     const int64_t prow = (base + j) * QB + row;
     const float w = fast_exp2((p.ws_ml[prow * 2] - M) * p.scale_log2);
     L += w * p.ws_ml[prow * 2 + 1];
-    const float* wo = p.ws_o + prow * 64 + half * 32;
-#pragma unroll
-    for (int i = 0; i < 32; i += 4) {
-      const f32x4 x = *(const f32x4*)(wo + i);
-      acc[i] += w * x[0]; acc[i + 1] += w * x[1]; acc[i + 2] += w * x[2]; acc[i + 3] += w * x[3];
-    }
+    const f32x4 x = *(const f32x4*)(p.ws_o + prow * 64 + grp * 4);
+    acc += x * w;
   }
   const float inv = 1.0f / L;
-  T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh + half * 32;
-#pragma unroll
-  for (int i = 0; i < 32; i += 8) {
-    f32x8 x;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = acc[i + e] * inv;
-    *(v8*)(op + i) = __builtin_convertvector(x, v8);
-  }
-  if (p.lse != nullptr && half == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = M * p.scale + __logf(L);
+  T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh + grp * 4;
+  *(v4*)op = __builtin_convertvector(acc * inv, v4);
+  if (p.lse != nullptr && grp == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = M * p.scale + __logf(L);
 }
 
 // Work plan: items = B*H*ceil(Lq/QB); every XCD owns ix = ceil(items/8) consecutive items and
@@ -626,7 +617,7 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   hipLaunchKernelGGL((shared_attn_fwd_pipe_kernel<T, NW, FOLD, ABL>), dim3(grid), dim3(NW * 64), 0, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || k <= 1) return e;
-  hipLaunchKernelGGL((shared_attn_combine_kernel<T, QB>), dim3(8 * rem), dim3(QB * 2), 0, s, p);
+  hipLaunchKernelGGL((shared_attn_combine_kernel<T, QB>), dim3(8 * rem, QB / 16), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
@@ -671,11 +662,11 @@ hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hip
 // combine launcher shared with the ping-pong kernel (p must carry the final sk_* / ws_* fields)
 hipError_t ir_launch_shared_attn_combine(const AttnKParams& p, int dtype, int qb, int rem, hipStream_t s) {
   if (qb == 256) {
-    if (dtype == 1) hipLaunchKernelGGL((shared_attn_combine_kernel<__bf16, 256>), dim3(8 * rem), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((shared_attn_combine_kernel<_Float16, 256>), dim3(8 * rem), dim3(512), 0, s, p);
+    if (dtype == 1) hipLaunchKernelGGL((shared_attn_combine_kernel<__bf16, 256>), dim3(8 * rem, 16), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((shared_attn_combine_kernel<_Float16, 256>), dim3(8 * rem, 16), dim3(256), 0, s, p);
   } else {
-    if (dtype == 1) hipLaunchKernelGGL((shared_attn_combine_kernel<__bf16, 128>), dim3(8 * rem), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((shared_attn_combine_kernel<_Float16, 128>), dim3(8 * rem), dim3(256), 0, s, p);
+    if (dtype == 1) hipLaunchKernelGGL((shared_attn_combine_kernel<__bf16, 128>), dim3(8 * rem, 8), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((shared_attn_combine_kernel<_Float16, 128>), dim3(8 * rem, 8), dim3(256), 0, s, p);
   }
   return hipGetLastError();
 }

@@ -1,5 +1,5 @@
 // shared_attn_fwd_w64.hip - 64-query-rows-per-wave variant of the fused extended self-attention
-// forward (gfx950), no AdaIN fold.  Same math, layouts and C-ABI contract as the other kernels.
+// forward (gfx950).  Same math, layouts and C-ABI contract as the other kernels.
 //
 // Why: ablation of the pipelined kernel attributes ~20 % of its time to LDS fragment reads and
 // ~10 % to staging + barriers - costs that are paid per wave per K/V tile.  Here every wave owns
@@ -21,9 +21,16 @@ struct RowBlock {
   f32x16 o0, o1;     // O^T accumulators (d = 32*db + crow(r,hi), column = query row)
   f32x2 la, lb;      // partial row sums
   float m_run;       // running (lazy) max of the raw scores
+  float l_done;      // FOLD: full row sum of the finished segments (la/lb then cover the current one)
 };
 
-template <typename T>
+// FOLD (AdaIN): no second accumulator set and no LDS totals - the accumulators live in a RATIO FRAME,
+//   acc' = (sum over finished segments of (a_s o O_s + b_s l_s) + a_cur o O_cur) / a_cur,
+// so the PV MFMAs of the current segment add straight into them; at a segment boundary
+//   acc' <- acc' * (a_cur / a_next) + l_cur * (b_cur / a_next)        (a = 1, b = 0 for the self segment)
+// and at the end a_next = 1 turns the frame into the true total.  a = (sigma_style + eps) /
+// (sigma_content + eps) is strictly positive; the lazy-max rescale is linear and touches acc' as before.
+template <typename T, bool FOLD>
 __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
@@ -134,6 +141,7 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
   for (int r = 0; r < 16; ++r) { A.o0[r] = 0.f; A.o1[r] = 0.f; Bk.o0[r] = 0.f; Bk.o1[r] = 0.f; }
   A.la = A.lb = Bk.la = Bk.lb = f32x2{0.f, 0.f};
   A.m_run = Bk.m_run = -INFINITY;
+  A.l_done = Bk.l_done = 0.f;
   const float c2 = p.scale_log2;
   const float lazy_thr = 6.0f / c2;
 
@@ -143,7 +151,7 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
     seg_b = p.include_self + r / p.tiles_ref;
     t0_b = r - (r / p.tiles_ref) * p.tiles_ref;
   }
-  int ct0 = t0_b;
+  int ct0 = t0_b, cseg = seg_b;
   const bool first_is_self = (p.include_self && seg_b == 0);
   int c_ntile = first_is_self ? p.tiles_self : p.tiles_ref;
   int c_len = first_is_self ? p.Ls : p.Lr;
@@ -177,6 +185,7 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
       for (int r = 0; r < 16; ++r) { R.o0[r] *= alpha; R.o1[r] *= alpha; }
       R.la *= alpha;
       R.lb *= alpha;
+      if (FOLD) R.l_done *= alpha;
       R.m_run = m_new;
     }
     const float mc = R.m_run * c2;
@@ -199,6 +208,44 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
     pk[0][1] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
     pk[1][0] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
     pk[1][1] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+  };
+
+  // FOLD: close segment `sc`; `has_next`: another (reference) segment follows in this piece
+  auto seg_row_sum = [&](RowBlock& R) {
+    float ls = (R.la[0] + R.la[1]) + (R.lb[0] + R.lb[1]);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+    ls = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    R.l_done += ls;
+    R.la = f32x2{0.f, 0.f};
+    R.lb = f32x2{0.f, 0.f};
+    return ls;
+  };
+  auto fold_boundary = [&](int sc, bool has_next) {
+    const float lsA = seg_row_sum(A), lsB = seg_row_sum(Bk);
+    const bool cur_ref = !(p.include_self && sc == 0);
+    const int64_t ao_c = ((int64_t)(b * p.N + (cur_ref ? sc - p.include_self : 0)) * p.H + h) * 64 + 4 * hi;
+    const int64_t ao_n = ((int64_t)(b * p.N + (has_next ? sc + 1 - p.include_self : 0)) * p.H + h) * 64 + 4 * hi;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      f32x4 ac0 = {1.f, 1.f, 1.f, 1.f}, ac1 = ac0, an0 = ac0, an1 = ac0, bc0 = {0.f, 0.f, 0.f, 0.f}, bc1 = bc0;
+      if (cur_ref) {
+        ac0 = *(const f32x4*)(p.aa + ao_c + 8 * g4); ac1 = *(const f32x4*)(p.aa + ao_c + 32 + 8 * g4);
+        bc0 = *(const f32x4*)(p.ab + ao_c + 8 * g4); bc1 = *(const f32x4*)(p.ab + ao_c + 32 + 8 * g4);
+      }
+      if (has_next) {
+        an0 = *(const f32x4*)(p.aa + ao_n + 8 * g4); an1 = *(const f32x4*)(p.aa + ao_n + 32 + 8 * g4);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 4 * g4 + i;
+        const float i0 = 1.0f / an0[i], i1 = 1.0f / an1[i];
+        const float sa0 = ac0[i] * i0, sb0 = bc0[i] * i0, sa1 = ac1[i] * i1, sb1 = bc1[i] * i1;
+        A.o0[r] = __builtin_fmaf(A.o0[r], sa0, lsA * sb0);
+        Bk.o0[r] = __builtin_fmaf(Bk.o0[r], sa0, lsB * sb0);
+        A.o1[r] = __builtin_fmaf(A.o1[r], sa1, lsA * sb1);
+        Bk.o1[r] = __builtin_fmaf(Bk.o1[r], sa1, lsB * sb1);
+      }
+    }
   };
 
   // ---- prologue ---------------------------------------------------------------------------------
@@ -253,17 +300,26 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
         Bk.o1 = Tr::mfma(v1, pkB[kb][ks], Bk.o1);
       }
     }
-    if (++ct0 == c_ntile) { ct0 = 0; c_ntile = p.tiles_ref; c_len = p.Lr; }
+    if (++ct0 == c_ntile) {
+      if (FOLD) fold_boundary(cseg, t + 1 < NTILES);
+      ct0 = 0; ++cseg; c_ntile = p.tiles_ref; c_len = p.Lr;
+    }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pair t+1 has landed
     __syncthreads();
   }
 
   // ---- epilogue (per row block) ---------------------------------------------------------------------
+  if (FOLD && ct0 != 0) fold_boundary(cseg, false);  // a piece that stops inside a segment closes what it has
   auto finish = [&](RowBlock& R, int qrow, int rowoff) {
-    float ls = (R.la[0] + R.la[1]) + (R.lb[0] + R.lb[1]);
-    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
-    const float l_fin = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    float l_fin;
+    if (FOLD) {
+      l_fin = R.l_done;
+    } else {
+      float ls = (R.la[0] + R.la[1]) + (R.lb[0] + R.lb[1]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+      l_fin = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
     if (npiece > 1) {
       const int64_t prow = ((int64_t)((xcd * (p.sk_ix - p.sk_full) + (item_local - p.sk_full)) * npiece + piece)) * QB + wid * 64 + rowoff + lq;
       float* wo = p.ws_o + prow * 64;
@@ -300,7 +356,7 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
   finish(Bk, qrowB, 32);
 }
 
-template <typename T>
+template <typename T, bool FOLD>
 hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   AttnKParams p = p0;
   constexpr int QB = 256;
@@ -326,7 +382,7 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.ws_o = p.ws;
   p.ws_ml = p.ws + (size_t)8 * rem * k * QB * 64;
   const int grid = 8 * (full + rem * k);
-  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T>), dim3(grid), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD>), dim3(grid), dim3(256), 0, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || k <= 1) return e;
   return ir_launch_shared_attn_combine(p, std::is_same<T, __bf16>::value ? 1 : 0, QB, rem, s);
@@ -334,7 +390,7 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
 
 }  // namespace
 
-// no AdaIN fold in this kernel: callers materialise V' first (ir_adain_apply) or pass no affine
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s) {
-  return dtype == 1 ? launch<__bf16>(p, s) : launch<_Float16>(p, s);
+  if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true>(p, s) : launch<_Float16, true>(p, s);
+  return dtype == 1 ? launch<__bf16, false>(p, s) : launch<_Float16, false>(p, s);
 }

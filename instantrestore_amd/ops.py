@@ -199,6 +199,15 @@ def time_shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: i
     return float(ms.value)
 
 
+def shared_attention_kernel_name(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
+                                 include_self: bool = True, adain=None) -> str:
+    """which kernel the dispatcher launches for these tensors (reporting only)"""
+    q, k_self, v_self, ref_k, ref_v = _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain)
+    out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=q.dtype, device=q.device)
+    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, None, True)
+    return _lib.lib().ir_shared_attn_kernel_name(C.byref(args)).decode()
+
+
 @_on_tensor_device
 def attn_probs(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True) -> torch.Tensor:
     """Materialise ``attention_probs`` (B, H, Lq, Lkv) from the LSE of the fused forward

@@ -13,7 +13,7 @@ for name, fill in (("random", None), ("zeros", 0.0), ("const", 0.37), ("random a
     else:
         q, k, v = (torch.full((B, L, C), fill, device="cuda", dtype=dt) for _ in range(3))
         rk = torch.full((B, N, L, C), fill, device="cuda", dtype=dt); rv = rk.clone()
-    for var in (10, 11, 10, 11):
+    for var in (10, 0, 10, 0):
         ops.set_attn_variant(var)
         aff = ops.adain_stats(v, rv, heads=H)
         ops.time_shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, iters=3, adain=aff)

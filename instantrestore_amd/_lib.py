@@ -88,6 +88,10 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with instantrestore_amd/csrc/build.sh "
                 "(or __graft_entry__.build()). There is no CPU fallback for this path."
             )
+        # torch ships its own libamdhip64; loading it FIRST makes the loader hand the same runtime to this
+        # library (same SONAME).  The other order puts two HIP runtimes in one process and the second one
+        # finds "no ROCm-capable device".
+        import torch  # noqa: F401
         try:
             handle = C.CDLL(LIB_PATH)
         except OSError as e:  # e.g. libamdhip64.so not found

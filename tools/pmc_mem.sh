@@ -7,11 +7,10 @@ R=$PWD; OUT=$R/gpurun_out/pmcm_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_LEVEL_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE"
 P2="SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD"
-P3="TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum TA_BUFFER_READ_LDS_WAVEFRONTS_sum"
-P4="TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TCP_GATE_EN1_sum"
+# (TA_* / TCP_* counter passes hung rocprofv3 on this pool - 15 GPU-minutes until the limit killed it - and are left out)
 P5="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_STALL_sum TCC_REQ_sum"
 i=0
-for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
+for P in "$P1" "$P2" "$P5"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT -o pass$i -- python "$@" > $OUT/pass$i.log 2>&1
 done

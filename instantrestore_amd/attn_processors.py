@@ -142,6 +142,24 @@ def _project_qkv(attn, st: _Prepared):
     return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
 
 
+def _project_kv_only(attn, st: _Prepared):
+    """``to_k`` / ``to_v`` alone (the last K/V-capture layer under early exit): the lower two thirds of
+    the cached fused weight when there is one, the two module calls otherwise."""
+    src = _kv_source(attn, st)
+    tk, tv = attn.to_k, attn.to_v
+    if st.encoder is None and not torch.is_grad_enabled():
+        effs = [_lora.effective_linear(m) for m in (attn.to_q, tk, tv)]
+        if all(e is not None and e[0].bias is None for e in effs) and \
+                effs[0][0].weight.shape == effs[1][0].weight.shape == effs[2][0].weight.shape:
+            dtype = _autocast_or(effs[0][0].weight, st.hidden)
+            w = _lora.cached_weight(attn, "_ir_qkv_cache", (attn.to_q, tk, tv), dtype)
+            c = w.shape[0] // 3
+            x = st.hidden if st.hidden.dtype == dtype else st.hidden.to(dtype)
+            kv = _linear(x, w[c:], None)
+            return kv[..., :c], kv[..., c:]
+    return tk(src), tv(src)
+
+
 def _project_out(attn, tokens: torch.Tensor) -> torch.Tensor:
     """``to_out[0]`` (attn_processors.py:267): one GEMM also when the module is a LoRA wrapper in
     inference state; the module call itself in training or when it cannot be folded."""
@@ -174,6 +192,12 @@ def _same_16bit(q: torch.Tensor, *others: Optional[torch.Tensor]) -> List[Option
 # ------------------------------------------------------------------------------------------
 # K/V-capturing processor of the frozen reference UNet (attn_processors.py:22-97)
 # ------------------------------------------------------------------------------------------
+class ReferenceCaptureComplete(Exception):
+    """raised by the LAST K/V-capturing processor when early exit is armed (``kv_harvest``): every
+    ``keys`` / ``values`` the main UNet will read is stashed, the rest of the reference UNet's forward
+    only produces an output the caller throws away (inference/test.py:100)"""
+
+
 class AttnProcessor(nn.Module):
     r"""Plain attention that stashes the PRE-head-split ``key`` / ``value`` projections
     ``(B*N, L, C)`` for later sharing (attn_processors.py:73-74)."""
@@ -182,6 +206,8 @@ class AttnProcessor(nn.Module):
         super().__init__()
         self.keys, self.values = None, None
         self.is_self_attn = None
+        self.stop_after_capture = None    # plain attribute (not a parameter / buffer): kv_harvest arms it with
+                                          # the list of all capturing processors of the UNet
 
     def reset(self):
         self.keys, self.values = None, None
@@ -190,6 +216,12 @@ class AttnProcessor(nn.Module):
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         self.is_self_attn = encoder_hidden_states is None
+        group = self.stop_after_capture
+        if group and all(p.keys is not None for p in group if p is not self):
+            # every other capturing layer has run: this is the last one, and only its to_k / to_v are still
+            # needed - no query, no attention, no out projection
+            self.keys, self.values = _project_kv_only(attn, st)
+            raise ReferenceCaptureComplete()
         query, key, value = _project_qkv(attn, st)
         self.keys, self.values = key, value  # consumed in place by the shared layers: no copies
         _same_16bit(query, key, value)

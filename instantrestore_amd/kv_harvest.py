@@ -46,9 +46,31 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
 
 
 def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, timestep, encoder_hidden_states,
-                                 n_refs: int, valid_indices: Sequence[int]):
+                                 n_refs: int, valid_indices: Sequence[int], early_exit: bool = False):
     """Run the frozen reference UNet on the (already encoded and noised) reference latents
     ``(B*N, 4, S, S)`` and harvest.  VAE encode/decode, the scheduler and the caption encoder
-    around it (pix2pix_turbo.py:244-257, 277-278) are stock PyTorch and out of scope."""
-    original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
+    around it (pix2pix_turbo.py:244-257, 277-278) are stock PyTorch and out of scope.
+
+    ``early_exit`` (off by default): the reference UNet's own output is
+    thrown away by the inference caller (``inference/test.py:100`` keeps only the K/V lists), so its
+    forward can stop at the last K/V-capturing layer - after ``to_k`` / ``to_v`` of that layer, before its
+    attention, its out projection and everything downstream.  The harvested lists are identical."""
+    if not early_exit:
+        original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
+        return harvest_reference_kv(original_unet, n_refs, valid_indices)
+    procs = [p for p in original_unet.attn_processors.values() if type(p) in [_ap.AttnProcessor]]
+    if not procs:
+        raise RuntimeError("no AttnProcessor on this UNet: call register_attention_processor_kv_unet first")
+    for p in procs:                          # whichever capturing layer runs last stops the forward
+        p.reset()
+        p.stop_after_capture = procs
+    try:
+        original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
+    except _ap.ReferenceCaptureComplete:
+        pass
+    else:
+        raise RuntimeError("early exit armed but the capturing layers did not all run")
+    finally:
+        for p in procs:
+            p.stop_after_capture = None
     return harvest_reference_kv(original_unet, n_refs, valid_indices)

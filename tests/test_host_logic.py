@@ -223,3 +223,33 @@ def test_product_has_no_cpu_fallback():
         if name.startswith("instantrestore_amd") or name.startswith("face_replace"):
             src = inspect.getsource(module) if hasattr(module, "__file__") and module.__file__ else ""
             assert "import oracle" not in src and "from oracle" not in src, name
+
+
+def test_reference_unet_early_exit_harvests_identical_kv(shim):
+    """the reference UNet's output is discarded by the inference caller, so its forward
+    may stop at the last K/V-capturing layer; the harvested lists must not change and nothing after that
+    layer may run."""
+    from face_replace.models.attn_processors import AttnProcessor, register_attention_processor_kv_unet
+    from instantrestore_amd.kv_harvest import get_conditioning_keys_values
+    from instantrestore_amd.unet_host import AttnTopologyUNet
+    import __graft_entry__ as ge
+    torch.manual_seed(0)
+    unet = AttnTopologyUNet(block_out_channels=(64, 128, 128, 128), attention_head_dim=(1, 2, 2, 2),
+                            cross_attention_dim=64, seed=5)
+    ge.register_attention_processor_kv_unet_default(unet, CFG)
+    register_attention_processor_kv_unet(unet)
+    x = torch.randn(4, 4, 16, 16)
+    text = torch.randn(4, 77, 64)
+    with torch.no_grad():
+        k_full, v_full = get_conditioning_keys_values(unet, x, None, text, 2, [2, 1])
+        n_full = len([c for c in shim.CALLS if c[0] == "shared_attention"])
+        shim.CALLS.clear()
+        k_early, v_early = get_conditioning_keys_values(unet, x, None, text, 2, [2, 1], early_exit=True)
+        n_early = len([c for c in shim.CALLS if c[0] == "shared_attention"])
+    assert len(k_full) == len(k_early) == 9
+    for a, b in zip(k_full + v_full, k_early + v_early):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert n_early < n_full                      # the last capture layer's attention and everything after it never ran
+    procs = [p for p in unet.attn_processors.values() if type(p) in [AttnProcessor]]
+    assert all(p.keys is None and p.stop_after_capture is None for p in procs)   # reset and disarmed
+    assert len(procs[-1].state_dict()) == 0

@@ -60,3 +60,20 @@ def test_linear_rejects_what_it_does_not_implement():
         ops.linear(x, w)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.linear(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(32, 64, dtype=torch.bfloat16))
+
+
+def test_linear_stress_full_size_against_vendor_gemm():
+    """the kernel keeps W chunks and result stores in flight across barriers and waits on COUNTED
+    s_waitcnt values: a miscount would show up as sporadically stale chunks.  Full top-layer size,
+    many launches back to back, every result compared with the vendor GEMM's."""
+    from instantrestore_amd import ops
+    torch.manual_seed(0)
+    w = (torch.randn(960, 320, device="cuda") / 18.0).to(torch.bfloat16)
+    wo = (torch.randn(320, 320, device="cuda") / 18.0).to(torch.bfloat16)
+    bo = torch.randn(320, device="cuda").to(torch.bfloat16)
+    for it in range(12):
+        x = torch.randn(131072 - 37 * it, 320, device="cuda").to(torch.bfloat16)   # ragged last row block too
+        y, ref = ops.linear(x, w), torch.nn.functional.linear(x, w)
+        assert (y.float() - ref.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref.float().abs().max().item()), it
+        y2, ref2 = ops.linear(x, wo, bo), torch.nn.functional.linear(x, wo, bo)
+        assert (y2.float() - ref2.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref2.float().abs().max().item()), it

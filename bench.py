@@ -77,30 +77,49 @@ def build_workload(cfg, train_input, dev, seed):
     return layers, (B, N, px, dtype, use_adain)
 
 
-def hot_path_step(layers, B, N, ref_early_exit=False):
-    """one pass: K/V capture -> harvest -> shared attention.  Returns the 9 outputs."""
+_REF_STREAM = {}
+
+
+def hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False):
+    """one pass: K/V capture -> harvest -> shared attention.  Returns the 9 outputs.
+
+    ``two_streams``: the reference UNet's layers run on their own HIP stream and shared layer i waits only
+    for the event of capture layer i (it reads nothing else), so the small layer classes - which cannot
+    fill 256 CUs on their own - overlap with the other UNet's kernels.  Same kernels, same work."""
     from instantrestore_amd.attn_processors import ReferenceCaptureComplete
+    cur = torch.cuda.current_stream()
+    ref_stream = cur
+    if two_streams:
+        ref_stream = _REF_STREAM.setdefault(cur.device, torch.cuda.Stream(device=cur.device))
+        ref_stream.wait_stream(cur)
     # 1. K/V capture on the reference token sets (--ref-early-exit: the reference UNet stops after to_k / to_v
     #    of its last capturing layer, SURVEY 8f rank 2 - NOT the default, the headline runs all nine in full)
     procs = [ly["kv_attn"].processor for ly in layers]
     for p in procs:
         p.stop_after_capture = procs if ref_early_exit else None
-    for ly in layers:
-        try:
-            ly["kv_attn"](ly["h_ref"])
-        except ReferenceCaptureComplete:
-            pass
+    for p in procs:
+        p.record_events = two_streams
+    with torch.cuda.stream(ref_stream):
+        for ly in layers:
+            try:
+                ly["kv_attn"](ly["h_ref"])
+            except ReferenceCaptureComplete:
+                pass
     # 2. harvest (views) + zero-fill of invalid references (valid = N at inference, test.py:81)
-    keys, vals = [], []
+    keys, vals, events = [], [], []
     for ly in layers:
         p = ly["kv_attn"].processor
         keys.append(p.keys.reshape(-1, N, p.keys.shape[1], p.keys.shape[2]))
         vals.append(p.values.reshape(-1, N, p.values.shape[1], p.values.shape[2]))
+        events.append(p.ready)
         p.reset()
-    # 3. shared attention on the degraded images
+    # 3. shared attention on the degraded images (each layer waits for its own reference layer's event)
     outs = []
     for ly in layers:
-        outs.append(ly["main_attn"](ly["h_main"], ref_keys=keys, ref_values=vals))
+        outs.append(ly["main_attn"](ly["h_main"], ref_keys=keys, ref_values=vals,
+                                    ref_events=events if two_streams else None))
+    if two_streams:
+        cur.wait_stream(ref_stream)
     return outs
 
 
@@ -209,6 +228,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B (ir_set_attn_variant); 0 = default")
+    ap.add_argument("--two-streams", type=int, default=1,
+                    help="1: reference-UNet layers on their own HIP stream, shared layer i waits for capture layer i only")
     ap.add_argument("--ref-early-exit", action="store_true",
                     help="stop the reference UNet after the K/V projections of its last capturing layer (its output is "
                          "discarded by the inference caller); off for the headline number")
@@ -240,11 +261,11 @@ def main():
 
     with torch.no_grad():
         for _ in range(args.warmup):
-            outs = hot_path_step(layers, B, N, args.ref_early_exit)
+            outs = hot_path_step(layers, B, N, args.ref_early_exit, bool(args.two_streams))
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            outs = hot_path_step(layers, B, N, args.ref_early_exit)
+            outs = hot_path_step(layers, B, N, args.ref_early_exit, bool(args.two_streams))
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
     assert all(torch.isfinite(o).all() for o in outs)
@@ -285,7 +306,7 @@ def main():
                             "attention, to_out) over B identities; UNet conv/ResNet and VAE stages are out of scope "
                             "and not in the step" % args.config,
                 "identities_per_gpu": B, "global_batch": total_ids, "refs": N, "px": px,
-                "use_adain": use_adain, "train_input": train_input, "ref_early_exit": bool(args.ref_early_exit), "parallelism": "dp%d (independent identities)" % world,
+                "use_adain": use_adain, "train_input": train_input, "ref_early_exit": bool(args.ref_early_exit), "two_streams": bool(args.two_streams), "parallelism": "dp%d (independent identities)" % world,
                 **{k: round(v, 1) for k, v in summary(N, train_input, px).items()},
             },
             "roofline": roof,

@@ -208,10 +208,18 @@ class AttnProcessor(nn.Module):
         self.is_self_attn = None
         self.stop_after_capture = None    # plain attribute (not a parameter / buffer): kv_harvest arms it with
                                           # the list of all capturing processors of the UNet
+        self.record_events = False        # True: record `ready` on the current stream once K/V are stashed
+        self.ready = None
 
     def reset(self):
         self.keys, self.values = None, None
         self.is_self_attn = None
+        self.ready = None
+
+    def _mark_ready(self):
+        if self.record_events and self.keys.is_cuda:
+            self.ready = torch.cuda.Event()
+            self.ready.record(torch.cuda.current_stream(self.keys.device))
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
@@ -221,9 +229,11 @@ class AttnProcessor(nn.Module):
             # every other capturing layer has run: this is the last one, and only its to_k / to_v are still
             # needed - no query, no attention, no out projection
             self.keys, self.values = _project_kv_only(attn, st)
+            self._mark_ready()
             raise ReferenceCaptureComplete()
         query, key, value = _project_qkv(attn, st)
         self.keys, self.values = key, value  # consumed in place by the shared layers: no copies
+        self._mark_ready()
         _same_16bit(query, key, value)
         tokens = _ops.shared_attention(query, key, value, heads=attn.heads, scale=attn.scale, include_self=True)
         return _epilogue(attn, st, tokens)
@@ -250,7 +260,7 @@ class FaceIDAttnProcessor(nn.Module):
         self.is_self_attn = None
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                ref_keys=None, ref_values=None):  # ref_* accepted and ignored, like the reference
+                ref_keys=None, ref_values=None, ref_events=None):  # ref_* accepted and ignored, like the reference
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         self.is_self_attn = encoder_hidden_states is None
         query = attn.to_q(st.hidden)
@@ -283,7 +293,7 @@ class SharedAttnProcessor(nn.Module):
         self.train_input = train_input
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                ref_keys=None, ref_values=None):
+                ref_keys=None, ref_values=None, ref_events=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         query, key, value = _project_qkv(attn, st)
 
@@ -293,6 +303,13 @@ class SharedAttnProcessor(nn.Module):
         if self.self_attn_idx is not None and ref_keys is not None and ref_values is not None:
             ref_k = ref_keys[self.self_attn_idx]
             ref_v = ref_values[self.self_attn_idx]
+            if ref_events is not None and ref_events[self.self_attn_idx] is not None:
+                # the reference UNet runs on another HIP stream (kv_harvest with_events): this layer needs
+                # capture layer `self_attn_idx` and nothing later
+                cur = torch.cuda.current_stream(ref_k.device)
+                cur.wait_event(ref_events[self.self_attn_idx])
+                ref_k.record_stream(cur)
+                ref_v.record_stream(cur)
             include_self = bool(self.train_input)
             if self.use_adain:
                 # style = this image's own post-projection V; content = each reference V

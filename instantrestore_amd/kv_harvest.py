@@ -21,14 +21,20 @@ from . import ops as _ops
 
 
 def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int],
-                         reset: bool = True) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+                         reset: bool = True, with_events: bool = False):
+    """``(keys, values)`` - or ``(keys, values, events)`` with ``with_events``: one HIP event per layer,
+    recorded by the capturing processor right after its K/V projections when ``record_events`` was set on
+    it (see :func:`enable_stream_overlap`); hand them to the main UNet as
+    ``cross_attention_kwargs={'ref_keys': ..., 'ref_values': ..., 'ref_events': ...}`` when the two UNets
+    run on different streams."""
     procs = [p for p in original_unet.attn_processors.values() if type(p) in [_ap.AttnProcessor]]
     if not procs:
         raise RuntimeError("no AttnProcessor on this UNet: call register_attention_processor_kv_unet first")
-    keys, values = [], []
+    keys, values, events = [], [], []
     for p in procs:
         if p.keys is None or p.values is None:
             raise RuntimeError("reference UNet has not been run since the last reset()")
+        events.append(p.ready)
         k = p.keys.reshape(-1, n_refs, p.keys.shape[1], p.keys.shape[2])
         v = p.values.reshape(-1, n_refs, p.values.shape[1], p.values.shape[2])
         keys.append(k)
@@ -42,7 +48,23 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
     if reset:
         for p in procs:
             p.reset()
+    if with_events:
+        if bool((valid < n_refs).any()):
+            # the zero fill above ran on the CURRENT stream after the captures: make it the thing to wait for
+            ev = torch.cuda.Event()
+            ev.record()
+            events = [ev] * len(keys)
+        return keys, values, events
     return keys, values
+
+
+def enable_stream_overlap(original_unet, enabled: bool = True) -> None:
+    """make every K/V-capturing processor of the reference UNet record a HIP event when its K/V are
+    stashed, so the main UNet (on another stream) can start each shared layer as soon as ITS reference
+    layer is done instead of after the whole reference forward"""
+    for p in original_unet.attn_processors.values():
+        if type(p) in [_ap.AttnProcessor]:
+            p.record_events = bool(enabled)
 
 
 def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, timestep, encoder_hidden_states,

@@ -1,0 +1,71 @@
+"""Two UNets on two HIP streams: shared layer i waits for the event of reference layer i only
+(kv_harvest.enable_stream_overlap / ref_events).  Same bytes as the single-stream run."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_stream_pipeline_equals_single_stream():
+    from face_replace.models.attn_processors import AttnProcessor, SharedAttnProcessor
+    from instantrestore_amd.attention import Attention
+    torch.manual_seed(7)
+    B, N, H, L = 2, 3, 2, 320
+    C = H * 64
+    dev, dt = "cuda", torch.bfloat16
+    layers = []
+    for i in range(3):
+        kv = Attention(query_dim=C, heads=H, dim_head=64, processor=AttnProcessor()).to(dev, dt)
+        main = Attention(query_dim=C, heads=H, dim_head=64,
+                         processor=SharedAttnProcessor(self_attn_idx=i, use_adain=True, train_input=True)).to(dev, dt)
+        layers.append((kv, main, torch.randn(B * N, L, C, device=dev, dtype=dt), torch.randn(B, L, C, device=dev, dtype=dt)))
+
+    def run(two_streams):
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream() if two_streams else cur
+        side.wait_stream(cur)
+        for kv, *_ in layers:
+            kv.processor.record_events = two_streams
+        with torch.no_grad():
+            with torch.cuda.stream(side):
+                for kv, _, h_ref, _ in layers:
+                    kv(h_ref)
+            keys, vals, events = [], [], []
+            for kv, *_ in layers:
+                p = kv.processor
+                keys.append(p.keys.reshape(B, N, L, C))
+                vals.append(p.values.reshape(B, N, L, C))
+                events.append(p.ready)
+                p.reset()
+            assert all((e is not None) == two_streams for e in events)
+            outs = [main(h, ref_keys=keys, ref_values=vals, ref_events=events if two_streams else None)
+                    for _, main, _, h in layers]
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        return outs
+
+    a = run(False)
+    for _ in range(3):      # repeated: a missing dependency would show up as a race, not deterministically
+        b = run(True)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
+def test_harvest_with_events_and_zero_fill():
+    from face_replace.models.attn_processors import register_attention_processor_kv_unet
+    from instantrestore_amd.kv_harvest import enable_stream_overlap, harvest_reference_kv
+    from instantrestore_amd.unet_host import AttnTopologyUNet
+    import __graft_entry__ as ge
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(use_adain=True, train_input=True, condition_on_face_embeds=False)
+    unet = AttnTopologyUNet(seed=3).to("cuda")
+    ge.register_attention_processor_kv_unet_default(unet, cfg)
+    register_attention_processor_kv_unet(unet)
+    enable_stream_overlap(unet)
+    text = torch.randn(4, 77, 1024, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        unet(torch.randn(4, 4, 16, 16, device="cuda"), None, encoder_hidden_states=text)
+        keys, vals, events = harvest_reference_kv(unet, 2, [2, 1], with_events=True)
+    assert len(keys) == len(vals) == len(events) == 9 and all(e is not None for e in events)
+    torch.cuda.synchronize()
+    assert float(keys[0][1, 1].abs().max()) == 0.0 and float(keys[0][0, 1].abs().max()) > 0.0   # zero fill of invalid refs

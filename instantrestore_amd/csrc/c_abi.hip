@@ -293,7 +293,7 @@ int ir_preprocess_lanczos_u8(const ir_image_desc* images, int32_t n_images, int3
       return fail(IR_ERR_INVALID_ARG, "image %d: bad tap tables / row range", i);
     if (d.col_first < 0 || d.col_count <= 0 || d.col_first + d.col_count > d.in_w)
       return fail(IR_ERR_INVALID_ARG, "image %d: bad column range", i);
-    if ((int64_t)d.col_count * 3 > 15000) return fail(IR_ERR_UNSUPPORTED, "image %d: more than 5000 source columns under the crop", i);
+    if ((int64_t)d.col_count * 3 > 60000) return fail(IR_ERR_UNSUPPORTED, "image %d: more than 20000 source columns under the crop", i);
     if (reinterpret_cast<uintptr_t>(d.tmp) & 3u) return fail(IR_ERR_UNSUPPORTED, "image %d: tmp must be 4-byte aligned", i);
   }
   for (int first = 0; first < n_images; first += kPreprocessImagesPerLaunch) {

@@ -93,7 +93,7 @@ __device__ __forceinline__ unsigned char clip8(int acc) {
 // their own start), then every thread produces whole pixels for all kHRows rows at once: a tap is
 // loaded once (tap-major table: neighbouring lanes, neighbouring ints) and used for kHRows x 3
 // multiply-adds; the three bytes of a source pixel come from one two-dword LDS read + v_alignbyte.
-constexpr int kHRows = 4;
+template <int kHRows>   // 4 normally; 1 when the span under the crop is too wide for four rows in LDS
 __global__ void __launch_bounds__(256) lanczos_horizontal_kernel(PreprocessKParams p, int pitch_dw) {
   extern __shared__ unsigned int lds_rows[];
   const ResampleImageK& im = p.img[blockIdx.y];
@@ -394,10 +394,14 @@ hipError_t launch_freeu_t(const void* x, void* out, int64_t planes, int H, int W
 
 hipError_t ir_launch_preprocess(const PreprocessKParams& p, int max_rows, int max_span_bytes, int max_ksize_v, int dtype,
                                 void* out, hipStream_t s) {
-  const unsigned hblocks = (unsigned)((max_rows + kHRows - 1) / kHRows);
   const int pitch_dw = (max_span_bytes + 3 + 3) / 4 + 4 + 3;   // + one tap group + the realignment window
-  const size_t lds = (size_t)pitch_dw * 4 * kHRows;
-  hipLaunchKernelGGL(lanczos_horizontal_kernel, dim3(hblocks, (unsigned)p.n), dim3(256), lds, s, p, pitch_dw);
+  if ((size_t)pitch_dw * 4 * 4 <= 60 * 1024) {
+    hipLaunchKernelGGL(lanczos_horizontal_kernel<4>, dim3((unsigned)((max_rows + 3) / 4), (unsigned)p.n), dim3(256),
+                       (size_t)pitch_dw * 4 * 4, s, p, pitch_dw);
+  } else {   // very wide sources: one row per workgroup keeps the staged span within LDS
+    hipLaunchKernelGGL(lanczos_horizontal_kernel<1>, dim3((unsigned)max_rows, (unsigned)p.n), dim3(256),
+                       (size_t)pitch_dw * 4, s, p, pitch_dw);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const unsigned bx = (unsigned)(((p.size * 3 + 3) / 4 + 255) / 256);

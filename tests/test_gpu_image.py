@@ -74,6 +74,16 @@ def test_preprocess_full_size_batch_equals_oracle():
     assert np.array_equal(out[3], lut[imgs[3]].transpose(2, 0, 1))
 
 
+def test_preprocess_very_wide_source_uses_the_one_row_path():
+    """a panorama whose span under the crop (> 5000 columns) does not fit four staged rows in LDS"""
+    from instantrestore_amd.preprocess import LanczosPreprocessor
+    rng = np.random.default_rng(11)
+    a = rng.integers(0, 256, (600, 9000, 3), dtype=np.uint8)
+    out = LanczosPreprocessor(512, torch.float32)([torch.from_numpy(a).cuda()]).cpu().numpy()
+    want, _ = IO.preprocess_np(a, 512)
+    assert np.array_equal(out[0], want)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16], ids=["f32", "f16", "bf16"])
 @pytest.mark.parametrize("shape,thr,scale", [((2, 1280, 8, 8), 1, 0.9), ((2, 1280, 16, 16), 1, 0.2), ((1, 640, 32, 32), 1, 0.2),
                                              ((1, 7, 64, 64), 1, 0.9), ((3, 5, 7, 10), 1, 0.5), ((1, 3, 16, 16), 2, 0.3),

@@ -69,3 +69,18 @@ def test_harvest_with_events_and_zero_fill():
     assert len(keys) == len(vals) == len(events) == 9 and all(e is not None for e in events)
     torch.cuda.synchronize()
     assert float(keys[0][1, 1].abs().max()) == 0.0 and float(keys[0][0, 1].abs().max()) > 0.0   # zero fill of invalid refs
+
+
+def test_synthetic_inference_example_runs_end_to_end():
+    """examples/synthetic_inference.py: preprocess -> reference branch (side stream, early exit) -> harvest
+    with events -> main branch -> tensor2im, on a narrow topology"""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "synthetic_inference.py")
+    spec = importlib.util.spec_from_file_location("synthetic_inference", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(["--identities", "2", "--refs", "3", "--px", "128", "--small"])
+    assert out.shape == (2, 128, 128, 3) and out.dtype == torch.uint8
+    out2 = mod.main(["--identities", "2", "--refs", "3", "--px", "128", "--small"])
+    assert torch.equal(out, out2)          # deterministic: same seeds, no race between the two streams

@@ -140,8 +140,18 @@ def _workspace(device: torch.device) -> torch.Tensor:
     return ws
 
 
+def _forward_only(*ts) -> None:
+    """the HIP path is the inference forward (test.py runs under ``torch.no_grad()``): a tensor that would
+    need a backward through it must not pass silently - the result would carry no ``grad_fn``"""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts):
+        raise NotImplementedError(
+            "instantrestore_amd ops are forward-only (inference hot path): run under torch.no_grad() / "
+            "inference_mode(); the training backward of the reference (coach.py) is out of scope")
+
+
 def _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain):
     _need_gpu(q, k_self, v_self, ref_k, ref_v)
+    _forward_only(q, k_self, v_self, ref_k, ref_v)
     q = _tok(q, heads, "q")
     if (ref_k is None) != (ref_v is None):
         raise ValueError("ref_k and ref_v must be given together")
@@ -232,6 +242,7 @@ def adain_stats(v_self: torch.Tensor, ref_v: torch.Tensor, *, heads: int, eps: f
     ``v_self`` (B, L, H*64) supplies the style statistics, ``ref_v`` (B, N, Lr, H*64) the content
     statistics (attn_processors.py:9-10, 244-245: token axis, unbiased std, eps on both)."""
     _need_gpu(v_self, ref_v)
+    _forward_only(v_self, ref_v)
     v_self, ref_v = _tok(v_self, heads, "v_self"), _ref(ref_v, heads, "ref_v")
     if v_self.dtype != ref_v.dtype:
         raise TypeError("v_self / ref_v dtype mismatch")
@@ -339,6 +350,7 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     """``F.linear(x, weight, bias)`` for 16-bit ``x (..., K)``, ``weight (N, K)`` with K <= 320
     (``ir_linear_fwd``): fp32 accumulation, one rounding.  Raises for unsupported shapes."""
     _need_gpu(x, weight, bias)
+    _forward_only(x, weight, bias)
     n, k = weight.shape
     x2 = x.reshape(-1, k)
     if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:

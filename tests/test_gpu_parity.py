@@ -474,3 +474,14 @@ def test_absolute_accuracy_on_unit_normal_activations(ops, dtype, variant, capsy
         print(f"\n[accuracy] variant {variant} {dtype}: max|O| {np.abs(ref).max():.3f} max|err| {err.max():.2e} mean|err| {err.mean():.2e}")
     bound = 1e-3 if dtype == torch.float16 else 2.0 ** -8 * max(1.0, np.abs(ref).max())
     assert err.max() <= bound * TOL_FACTOR.get(variant, 1.0), (err.max(), bound)
+
+
+def test_training_mode_is_refused_loudly(ops):
+    """forward-only path: tensors that need a backward must not pass silently (no grad_fn would come out)"""
+    q = torch.randn(1, 64, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True)
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        ops.shared_attention(q, q, q, heads=1, scale=0.125)
+    with torch.no_grad():
+        ops.shared_attention(q, q, q, heads=1, scale=0.125)
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        ops.linear(q.reshape(64, 64), torch.zeros(32, 64, device="cuda", dtype=torch.bfloat16))

@@ -136,6 +136,44 @@ __global__ void __launch_bounds__(64) adain_finalize_kernel(const AdainKParams p
   p.b[o] = mu_v - mu_x * a;
 }
 
+// Same result, one workgroup per (b, h): the (1+N) x nchunk partials are first pulled into LDS with
+// independent coalesced loads (the per-channel loop above waits for a fresh cache miss per chunk), then
+// merged from LDS.  Used when they fit in `lds_floats` of dynamic shared memory.
+__global__ void __launch_bounds__(256) adain_finalize_staged_kernel(const AdainKParams p) {
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  const int tid = threadIdx.x;
+  const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
+  const int per_mat = p.nchunk * 128;
+  for (int j = 0; j <= p.N; ++j) {
+    const float* g = p.ws + (((int64_t)(b * (1 + p.N) + j) * p.H + h) * p.nchunk) * 128;
+    for (int i = tid * 4; i < per_mat; i += 256 * 4) *(f32x4*)&fsm[j * per_mat + i] = *(const f32x4*)&g[i];
+  }
+  __syncthreads();
+  float* stats = fsm + (1 + p.N) * per_mat;   // [(1+N)][mean 64 | M2 64]
+  for (int i = tid; i < (1 + p.N) * 64; i += 256) {
+    const int j = i >> 6, d = i & 63;
+    const int len = j == 0 ? p.Ls : p.Lr;
+    const int nch = (len + ROWS - 1) / ROWS;
+    float cn = 0.f, mean = 0.f, m2 = 0.f;
+    for (int c = 0; c < nch; ++c) {
+      const int rows = (c + 1) * ROWS <= len ? ROWS : len - c * ROWS;
+      chan_merge(cn, mean, m2, (float)rows, fsm[j * per_mat + c * 128 + d], fsm[j * per_mat + c * 128 + 64 + d]);
+    }
+    stats[j * 128 + d] = mean;
+    stats[j * 128 + 64 + d] = m2;
+  }
+  __syncthreads();
+  for (int i = tid; i < p.N * 64; i += 256) {
+    const int n = i >> 6, d = i & 63;
+    const float sd_v = sqrtf(stats[64 + d] / (float)(p.Ls - 1)) + p.eps;
+    const float sd_x = sqrtf(stats[(1 + n) * 128 + 64 + d] / (float)(p.Lr - 1)) + p.eps;
+    const float a = sd_v / sd_x;
+    const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
+    p.a[o] = a;
+    p.b[o] = stats[d] - stats[(1 + n) * 128 + d] * a;
+  }
+}
+
 // grid: (B*(1+N)*H); 64 threads. Plain token statistics (mean, unbiased std) of every matrix.
 __global__ void __launch_bounds__(64) token_stats_finalize_kernel(const AdainKParams p) {
   const int d = threadIdx.x;
@@ -203,7 +241,10 @@ hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s
   else hipLaunchKernelGGL((adain_partial_kernel<_Float16>), grid, dim3(AT), 0, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(adain_finalize_kernel, dim3(p.B * p.N * p.H), dim3(64), 0, s, p);
+  const size_t lds = (size_t)(1 + p.N) * (p.nchunk * 128 + 128) * sizeof(float);
+  // (short token axes have one or two chunks: nothing to overlap, and more, smaller workgroups win)
+  if (p.nchunk >= 8 && lds <= 60 * 1024) hipLaunchKernelGGL(adain_finalize_staged_kernel, dim3(p.B * p.H), dim3(256), lds, s, p);
+  else hipLaunchKernelGGL(adain_finalize_kernel, dim3(p.B * p.N * p.H), dim3(64), 0, s, p);
   return hipGetLastError();
 }
 

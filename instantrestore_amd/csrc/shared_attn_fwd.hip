@@ -451,6 +451,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   if (base == 10) return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);  // default + lazy max (deferred rescale)
   if (base == 11) return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);  // + pre-scaled Q, reference through the MFMA C operand
   if (base == 12) return ir_launch_shared_attn_fwd_w64(p, dtype, s);  // 64 rows per wave
+  if (base == 14) return ir_launch_shared_attn_fwd_pipe(p, dtype, 14, s);  // pipelined, QK^T of the next tile issued before the row max
   if (base == 8) return ir_launch_shared_attn_fwd_pp(p, dtype, s);  // ping-pong wave groups (shared_attn_fwd_pp.hip)
   const int nw = (base == 1) ? 8 : 4;
   return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);

@@ -315,6 +315,17 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
       qk(c0, c1, t & 1);
       asm volatile("s_nop 7\n\ts_nop 4" : "+v"(c0), "+v"(c1));  // MFMA -> asm v_max3 hazard pad
     }
+    // EARLYQK: the prefetch issue and S(t+1) = K[t+1] Q^T go FIRST, so the row-max chain and the rescale
+    // test of S(t) - 40-odd dependent VALU operations that used to run with the matrix pipe idle - execute
+    // beside the eight QK^T MFMAs (S is double-buffered: n0/n1 are not the registers read below)
+    constexpr bool EARLYQK = (ABL & 4096) != 0 && !PRESC && !NOPIPE;
+    if (EARLYQK) {
+      if (has2) {
+        if (DMA) issue_dma(t & 1, (vcur >= 1) ? vcur - 1 : 2);
+        else issue_loads();
+      }
+      if (has1) qk(n0, n1, (t + 1) & 1);
+    }
     // (1) ragged tail of a segment: mask keys past its end (wave-uniform branch, rare)
     const int valid = c_len - ct0 * KVB;
     if (valid < KVB) {
@@ -369,11 +380,11 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     const float mc = (LAZYMAX ? m_run : m_new) * c2;
     // (4) the overlapped block: prefetch issue, S(t+1) on the matrix pipe, exp/pack on the VALU,
     //     PV(t) on the matrix pipe
-    if (!NOPIPE && has2 && !(ABL & 4)) {
+    if (!EARLYQK && !NOPIPE && has2 && !(ABL & 4)) {
       if (DMA) issue_dma(t & 1, (vcur >= 1) ? vcur - 1 : 2);  // K slot (t+2)&1, V slot (vcur+2)%3: both free since the last barrier
       else issue_loads();
     }
-    if (!NOPIPE && has1) qk(n0, n1, (t + 1) & 1);
+    if (!EARLYQK && !NOPIPE && has1) qk(n0, n1, (t + 1) & 1);
     const f32x2 cc = {c2, c2};
     const f32x2 nm = {-mc, -mc};
     if (!(ABL & 8))
@@ -629,6 +640,7 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   if (nw == 7) return fold ? launch<T, 4, true, 128>(p, s) : launch<T, 4, false, 128>(p, s);  // LDS-DMA from asm
   if (nw == 10) return fold ? launch<T, 4, true, 128 | 1024>(p, s) : launch<T, 4, false, 128 | 1024>(p, s);  // asm DMA + lazy max
   if (nw == 11) return fold ? launch<T, 4, true, 128 | 1024 | 2048>(p, s) : launch<T, 4, false, 128 | 1024 | 2048>(p, s);  // + pre-scaled Q, reference through the C operand
+  if (nw == 14) return fold ? launch<T, 4, true, 128 | 1024 | 4096>(p, s) : launch<T, 4, false, 128 | 1024 | 4096>(p, s);  // + QK^T of the next tile first
   if (nw == 9) return fold ? launch<T, 4, true, 256>(p, s) : launch<T, 4, false, 256>(p, s);  // straight schedule, 3 waves/SIMD
   return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
 }

@@ -36,8 +36,15 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
   using v8 = typename Tr::v8;
   using v4 = typename Tr::v4;
   constexpr int NW = 4, NT = 256, QB = 256, CH = 2;
-  constexpr int K_OFF = 0, V_OFF = 2 * TILE_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+  // K/V rings of RING tiles each: pair t+RING-1 is in flight while tile t is computed.  RING = 3 (two tile
+  // times for a transfer to land) measured equal on plain attention and 5 % slower with the fold (same box):
+  // the transfers are not what the waves wait for.  Kept as a build-time switch (-DW64_RING=3).
+#ifndef W64_RING
+#define W64_RING 2
+#endif
+  constexpr int RING = W64_RING;
+  constexpr int K_OFF = 0, V_OFF = RING * TILE_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RING * TILE_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -255,14 +262,16 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
 #pragma unroll
   for (int c = 0; c < CH; ++c) { kvo[c] += (unsigned)(t0 * kstep); vvo[c] += (unsigned)(t0 * vstep); }
   issue_pair(0);
+  if (RING == 3 && NTILES > 1) issue_pair(1);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qA[ks]), "v"(qB[ks]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  int cur = 0;
   for (int t = 0; t < NTILES; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < NTILES) issue_pair(cur ^ 1);  // pair t+1: its slot was last read in step t-1
+    // pair t+RING-1 goes into the slot that was last read in step t-1
+    if (t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
 
     // ---- S^T = K Q^T for both row blocks: every K fragment is fetched once, used twice ----------
     const unsigned char* Kb = smem + K_OFF + cur * TILE_BYTES;
@@ -305,8 +314,12 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
       ct0 = 0; ++cseg; c_ntile = p.tiles_ref; c_len = p.Lr;
     }
 
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pair t+1 has landed
+    // pair t+1 has landed; with RING = 3 the 2*CH transfers of pair t+2, issued in this step, stay in flight
+    // (vector memory operations retire in issue order and nothing else was issued after them)
+    if (RING == 3 && t + 2 < NTILES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    cur = (RING == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
   }
 
   // ---- epilogue (per row block) ---------------------------------------------------------------------

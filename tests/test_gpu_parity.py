@@ -485,3 +485,35 @@ def test_training_mode_is_refused_loudly(ops):
         ops.shared_attention(q, q, q, heads=1, scale=0.125)
     with pytest.raises(NotImplementedError, match="forward-only"):
         ops.linear(q.reshape(64, 64), torch.zeros(32, 64, device="cuda", dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("variant", [0, 12], ids=["default", "w64"])
+def test_massive_activation_channels(ops, dtype, variant):
+    """diffusion UNets carry a few channels that are tens of times larger than the rest: scores with a
+    heavy tail (lazy max must still move when it has to), reference V with an outlier channel (AdaIN
+    scales of very different magnitude next to each other: the ratio frame multiplies by a_cur/a_next),
+    one near-constant style channel (a -> eps/(sigma+eps)) and one all-zero reference (a -> (sigma+eps)/eps)."""
+    g = torch.Generator().manual_seed(17)
+    B, H, L, N = 1, 2, 320, 3
+    C = H * 64
+    q, k = torch.randn(B, L, C, generator=g), torch.randn(B, L, C, generator=g)
+    rk = torch.randn(B, N, L, C, generator=g)
+    for t in (q, k, rk):
+        t[..., 5] *= 6.0
+        t[..., 70] *= 9.0
+    v = torch.randn(B, L, C, generator=g)
+    rv = torch.randn(B, N, L, C, generator=g)
+    v[..., 3] = 0.7 + 1e-3 * torch.randn(B, L, generator=g)        # almost constant style channel
+    rv[..., 9] *= 30.0                                              # outlier content channel
+    rv[:, 1, :, 64:] = 0.0                                          # one reference head entirely zero
+    q, k, v, rk, rv = (t.to(dtype) for t in (q, k, v, rk, rv))
+    ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.125, True, True)
+    c = lambda t: t.cuda()
+    ops.set_attn_variant(variant)
+    try:
+        aff = ops.adain_stats(c(v), c(rv), heads=H)
+        out = ops.shared_attention(c(q), c(k), c(v), c(rk), c(rv), heads=H, scale=0.125, include_self=True, adain=aff)
+    finally:
+        ops.set_attn_variant(0)
+    _check(out, ref, dtype, "massive activations")

@@ -96,9 +96,10 @@ const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
   const int v = g_variant.load() & 15;
   const bool fold = p.aa != nullptr;
   switch (v) {
-    case 0: return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave>")
+    case 0: return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>")
                                              : (fold ? "shared_attn_fwd_pipe_kernel<4 waves, lazy max, AdaIN fold>" : "shared_attn_fwd_pipe_kernel<4 waves, lazy max>");
-    case 12: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave>";
+    case 12: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves>";
+    case 13: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>";
     case 11: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q>";
     case 10: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max>";
     case 8: return "shared_attn_fwd_pp_kernel";
@@ -106,7 +107,8 @@ const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
   }
 }
 
-size_t ir_shared_attn_workspace_bytes(void) { return (size_t)8 * 64 * 256 * 66 * sizeof(float); }
+// 8 XCDs x 64 pieces x 512 rows x (64 + 2) floats: the largest remainder split of any kernel (512-row items)
+size_t ir_shared_attn_workspace_bytes(void) { return (size_t)8 * 64 * 512 * 66 * sizeof(float); }
 
 int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream) {
   AttnKParams p;

@@ -86,7 +86,23 @@ hipError_t ir_launch_shared_attn_fwd_pipe(const AttnKParams& p, int dtype, int n
 hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hipStream_t s);
 hipError_t ir_launch_shared_attn_combine(const AttnKParams& p, int dtype, int qb, int rem, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s);
-bool ir_attn_default_is_w64(const AttnKParams& p);   // the default dispatch rule (variant 0)
+hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s);
+bool ir_attn_default_is_w64(const AttnKParams& p);
+
+// Remainder split: `rem` items of the last, partially filled round (per XCD) on `slots` concurrently
+// resident workgroups.  Cutting each into k K/V-range pieces makes the round last ceil(rem*k/slots)/k of an
+// item; pick the k that minimises it (plus a small per-piece charge for the fp32 partials and the combine),
+// within the piece-length floor `kmax` and the workspace capacity `cap_pieces` (pieces per XCD).
+static inline int ir_pick_split(int rem, int slots, int kmax, long cap_pieces) {
+  int best_k = 1;
+  double best = 1.0;   // k = 1: one round of whole items
+  for (int k = 2; k <= kmax && (long)rem * k <= cap_pieces; ++k) {
+    const int rounds = (rem * k + slots - 1) / slots;
+    const double t = (double)rounds / k + 0.012 * k;
+    if (t < best - 1e-9) { best = t; best_k = k; }
+  }
+  return best_k;
+}   // the default dispatch rule (variant 0)
 hipError_t ir_launch_shared_attn_fwd_pp(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s);

@@ -412,9 +412,12 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 //   9 straight schedule + asm DMA at 3 waves/SIMD   12 64 query rows per wave, no fold (shared_attn_fwd_w64.hip)
 // (tried and removed, see DESIGN.md 4.1: hoisted fragment reads, s_setprio, single-statement asm VALU)
 // variant >> 4: ablation bits - only in -DIR_ABLATIONS builds (timing experiments, WRONG results)
+// Default dispatch: the 64-rows-per-wave kernel in 8-wave (512-row) workgroups on the long query axes when
+// there is enough work to fill the chip with them - at least one full round of 512-row items, or long K/V
+// sequences whose remainder split fills it (the shared layers) - the pipelined 32-row kernel otherwise.
 bool ir_attn_default_is_w64(const AttnKParams& p) {
-  const long items256 = (long)p.B * p.H * ((p.Lq + 255) / 256);
-  return p.Lq >= 4096 && items256 >= 256;
+  const long items512 = (long)p.B * p.H * ((p.Lq + 511) / 512);
+  return p.Lq >= 4096 && (items512 >= 256 || p.ntiles >= 128);
 }
 
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
@@ -435,12 +438,12 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
 #endif
   const int base = variant & 15;
   if (base == 0) {
-    // default: the 64-rows-per-wave kernel (AdaIN folded in a ratio frame) on the long query axes of the
-    // 64x64-token class and above, where it measured 5-6 % faster with and without the fold once there is
-    // at least one full round of 256-row workgroups; the software-pipelined 32-row kernel (4 waves, asm-issued
+    // default: the 64-rows-per-wave kernel (AdaIN folded in a ratio frame, 512-row workgroups: half the K/V
+    // transfers per row of the 256-row form and 3-8 % faster wherever both were measured) on the long query
+    // axes of the 64x64-token class and above; the software-pipelined 32-row kernel (4 waves, asm-issued
     // LDS-DMA staging, lazy max, LDS-resident fold totals) everywhere else - short axes leave the wide
-    // kernel's 256-row items too few to fill the chip
-    if (ir_attn_default_is_w64(p)) return ir_launch_shared_attn_fwd_w64(p, dtype, s);
+    // kernel too few items to fill the chip
+    if (ir_attn_default_is_w64(p)) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
     return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);
   }
   if (base == 3) return ir_launch_shared_attn_fwd_pipe(p, dtype, 4, s);  // software-pipelined, 4 waves, register staging
@@ -451,6 +454,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   if (base == 10) return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);  // default + lazy max (deferred rescale)
   if (base == 11) return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);  // + pre-scaled Q, reference through the MFMA C operand
   if (base == 12) return ir_launch_shared_attn_fwd_w64(p, dtype, s);  // 64 rows per wave
+  if (base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);  // 64 rows per wave, 8-wave (512-row) workgroups
   if (base == 14) return ir_launch_shared_attn_fwd_pipe(p, dtype, 14, s);  // pipelined, QK^T of the next tile issued before the row max
   if (base == 8) return ir_launch_shared_attn_fwd_pp(p, dtype, s);  // ping-pong wave groups (shared_attn_fwd_pp.hip)
   const int nw = (base == 1) ? 8 : 4;

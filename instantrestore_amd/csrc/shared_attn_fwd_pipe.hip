@@ -611,13 +611,8 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   int rem = p.sk_ix - full;
   int k = 1;
   if (p.ws != nullptr && rem > 0) {
-    k = slots_x / rem;
-    const int kmax = p.ntiles / 8;  // keep pieces at least 8 tiles long
-    if (k > kmax) k = kmax;
     const size_t piece_bytes = (size_t)QB * 66 * sizeof(float);
-    const size_t cap = p.ws_bytes / piece_bytes;  // pieces the caller's workspace can hold
-    if ((size_t)8 * rem * k > cap) k = (int)(cap / ((size_t)8 * rem));
-    if (k < 1) k = 1;
+    k = ir_pick_split(rem, slots_x, p.ntiles / 8 /* pieces of at least 8 tiles */, (long)(p.ws_bytes / piece_bytes / 8));
   }
   if (k <= 1) { full = p.sk_ix; rem = 0; k = 1; }
   p.sk_full = full;
@@ -673,7 +668,10 @@ hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hip
 
 // combine launcher shared with the ping-pong kernel (p must carry the final sk_* / ws_* fields)
 hipError_t ir_launch_shared_attn_combine(const AttnKParams& p, int dtype, int qb, int rem, hipStream_t s) {
-  if (qb == 256) {
+  if (qb == 512) {
+    if (dtype == 1) hipLaunchKernelGGL((shared_attn_combine_kernel<__bf16, 512>), dim3(8 * rem, 32), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((shared_attn_combine_kernel<_Float16, 512>), dim3(8 * rem, 32), dim3(256), 0, s, p);
+  } else if (qb == 256) {
     if (dtype == 1) hipLaunchKernelGGL((shared_attn_combine_kernel<__bf16, 256>), dim3(8 * rem, 16), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((shared_attn_combine_kernel<_Float16, 256>), dim3(8 * rem, 16), dim3(256), 0, s, p);
   } else {

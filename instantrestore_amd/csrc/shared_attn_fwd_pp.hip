@@ -398,13 +398,8 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   int rem = p.sk_ix - full;
   int k = 1;
   if (p.ws != nullptr && rem > 0) {
-    k = slots_x / rem;
-    const int kmax = p.ntiles / 8;
-    if (k > kmax) k = kmax;
     const size_t piece_bytes = (size_t)QB * 66 * sizeof(float);
-    const size_t cap = p.ws_bytes / piece_bytes;
-    if ((size_t)8 * rem * k > cap) k = (int)(cap / ((size_t)8 * rem));
-    if (k < 1) k = 1;
+    k = ir_pick_split(rem, slots_x, p.ntiles / 8 /* pieces of at least 8 tiles */, (long)(p.ws_bytes / piece_bytes / 8));
   }
   if (k <= 1) { full = p.sk_ix; rem = 0; k = 1; }
   p.sk_full = full;

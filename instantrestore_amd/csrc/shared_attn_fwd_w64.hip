@@ -30,12 +30,12 @@ struct RowBlock {
 //   acc' <- acc' * (a_cur / a_next) + l_cur * (b_cur / a_next)        (a = 1, b = 0 for the self segment)
 // and at the end a_next = 1 turns the frame into the true total.  a = (sigma_style + eps) /
 // (sigma_content + eps) is strictly positive; the lazy-max rescale is linear and touches acc' as before.
-template <typename T, bool FOLD>
-__global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnKParams p) {
+template <typename T, bool FOLD, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
   using v4 = typename Tr::v4;
-  constexpr int NW = 4, NT = 256, QB = 256, CH = 2;
+  constexpr int NT = NW * 64, QB = NW * 64, CH = 512 / NT;
   // K/V rings of RING tiles each: pair t+RING-1 is in flight while tile t is computed.  RING = 3 (two tile
   // times for a transfer to land) measured equal on plain attention and 5 % slower with the fold (same box):
   // the transfers are not what the waves wait for.  Kept as a build-time switch (-DW64_RING=3).
@@ -369,25 +369,20 @@ __global__ void __launch_bounds__(256, 2) shared_attn_fwd_w64_kernel(const AttnK
   finish(Bk, qrowB, 32);
 }
 
-template <typename T, bool FOLD>
+template <typename T, bool FOLD, int NW = 4>
 hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   AttnKParams p = p0;
-  constexpr int QB = 256;
+  constexpr int QB = NW * 64;
   p.nqb = (p.Lq + QB - 1) / QB;
   p.sk_items = p.B * p.H * p.nqb;
   p.sk_ix = (p.sk_items + 7) / 8;
-  const int slots_x = 64;  // two 4-wave workgroups per CU
+  const int slots_x = 32 * (8 / NW);  // 8 waves per CU: two 4-wave workgroups (or one 8-wave one)
   int full = (p.sk_ix / slots_x) * slots_x;
   int rem = p.sk_ix - full;
   int k = 1;
   if (p.ws != nullptr && rem > 0) {
-    k = slots_x / rem;
-    const int kmax = p.ntiles / 8;
-    if (k > kmax) k = kmax;
     const size_t piece_bytes = (size_t)QB * 66 * sizeof(float);
-    const size_t cap = p.ws_bytes / piece_bytes;
-    if ((size_t)8 * rem * k > cap) k = (int)(cap / ((size_t)8 * rem));
-    if (k < 1) k = 1;
+    k = ir_pick_split(rem, slots_x, p.ntiles / 8 /* pieces of at least 8 tiles */, (long)(p.ws_bytes / piece_bytes / 8));
   }
   if (k <= 1) { full = p.sk_ix; rem = 0; k = 1; }
   p.sk_full = full;
@@ -395,13 +390,18 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.ws_o = p.ws;
   p.ws_ml = p.ws + (size_t)8 * rem * k * QB * 64;
   const int grid = 8 * (full + rem * k);
-  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD>), dim3(grid), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW>), dim3(grid), dim3(NW * 64), 0, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || k <= 1) return e;
   return ir_launch_shared_attn_combine(p, std::is_same<T, __bf16>::value ? 1 : 0, QB, rem, s);
 }
 
 }  // namespace
+
+hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s) {  // 8-wave (512-row) workgroups
+  if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8>(p, s) : launch<_Float16, true, 8>(p, s);
+  return dtype == 1 ? launch<__bf16, false, 8>(p, s) : launch<_Float16, false, 8>(p, s);
+}
 
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s) {
   if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true>(p, s) : launch<_Float16, true>(p, s);

@@ -404,12 +404,16 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 
 }  // namespace
 
-// variant & 15 selects the kernel (tuning hook; 0 = default):
-//   0/10 software-pipelined, 4 waves, asm-issued LDS-DMA staging, lazy max (shared_attn_fwd_pipe.hip)
-//   7 the same with an exact (every-change) rescale
+// variant & 15 selects the kernel (tuning hook; 0 = default dispatch, see ir_attn_default_is_w64):
+//   13 64 query rows per wave, 8-wave (512-row) workgroups (shared_attn_fwd_w64.hip; default on long axes)
+//   12 the same in 4-wave (256-row) workgroups
+//   10 software-pipelined 32-row kernel, 4 waves, asm-issued LDS-DMA staging, lazy max (shared_attn_fwd_pipe.hip;
+//      default everywhere else)        7 the same with an exact (every-change) rescale
+//   11 10 + pre-scaled Q, reference through the MFMA C operand (opt-in fast mode: one more rounding of Q)
+//   14 10 with the next tile's QK^T issued before the row max
 //   1/2 this file's straight-line kernel with 8 / 4 waves     3/4 pipelined, register staging, 4 / 8 waves
 //   6 pipelined + builtin LDS-DMA   8 ping-pong wave groups (shared_attn_fwd_pp.hip)
-//   9 straight schedule + asm DMA at 3 waves/SIMD   12 64 query rows per wave, no fold (shared_attn_fwd_w64.hip)
+//   9 straight schedule + asm DMA at 3 waves/SIMD
 // (tried and removed, see DESIGN.md 4.1: hoisted fragment reads, s_setprio, single-statement asm VALU)
 // variant >> 4: ablation bits - only in -DIR_ABLATIONS builds (timing experiments, WRONG results)
 // Default dispatch: the 64-rows-per-wave kernel in 8-wave (512-row) workgroups on the long query axes when

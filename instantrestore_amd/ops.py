@@ -417,5 +417,6 @@ def preprocess_lanczos(descs, size: int, dtype: torch.dtype, device: torch.devic
 
 
 def set_attn_variant(variant: int) -> int:
-    """tuning hook for benchmarks/tests (0 = auto, 1 = 8-wave, 2 = 4-wave workgroups)"""
+    """tuning hook for benchmarks/tests: 0 = default dispatch, 13 / 12 = 64-row kernel in 8- / 4-wave workgroups,
+    10 = pipelined 32-row kernel, 11 = opt-in pre-scaled-Q fast mode, ... (csrc/shared_attn_fwd.hip lists them)"""
     return _lib.lib().ir_set_attn_variant(int(variant))

@@ -266,7 +266,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             outs = hot_path_step(layers, B, N, args.ref_early_exit, bool(args.two_streams))
-        torch.cuda.synchronize()
+        barrier()   # synchronize + barrier + synchronize: the K steps are bracketed on both sides
         elapsed = time.perf_counter() - t0
     assert all(torch.isfinite(o).all() for o in outs)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

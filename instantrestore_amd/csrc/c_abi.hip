@@ -97,7 +97,7 @@ const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
   const bool fold = p.aa != nullptr;
   switch (v) {
     case 0: return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>")
-                                             : (fold ? "shared_attn_fwd_pipe_kernel<4 waves, lazy max, AdaIN fold>" : "shared_attn_fwd_pipe_kernel<4 waves, lazy max>");
+                                             : (fold ? "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK, AdaIN fold>" : "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK>");
     case 12: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves>";
     case 13: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>";
     case 11: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q>";

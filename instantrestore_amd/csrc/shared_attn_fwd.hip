@@ -448,7 +448,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
     // LDS-DMA staging, lazy max, LDS-resident fold totals) everywhere else - short axes leave the wide
     // kernel too few items to fill the chip
     if (ir_attn_default_is_w64(p)) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
-    return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);
+    return ir_launch_shared_attn_fwd_pipe(p, dtype, 14, s);   // 10 + next tile's QK^T before the row max: +1-3 % on the short axes
   }
   if (base == 3) return ir_launch_shared_attn_fwd_pipe(p, dtype, 4, s);  // software-pipelined, 4 waves, register staging
   if (base == 4) return ir_launch_shared_attn_fwd_pipe(p, dtype, 8, s);  // software-pipelined, 8 waves

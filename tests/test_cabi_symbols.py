@@ -67,3 +67,15 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.ir_adain_stats_workspace_bytes(8, 5, 4096, 4, 4096) == 8 * 5 * 5 * 16 * 128 * 4
     with pytest.raises(_lib.IRError):
         _lib.check(-1, "demo")
+
+
+def test_variant_env_var_is_applied_at_load():
+    """IR_ATTN_VARIANT=<n> selects a kernel variant for the whole process without code changes"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); from instantrestore_amd import _lib; "
+            "print(_lib.lib().ir_set_attn_variant(0))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, IR_ATTN_VARIANT="11")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.strip().splitlines()[-1] == "11"

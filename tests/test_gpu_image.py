@@ -123,3 +123,18 @@ def test_apply_freeu_contract():
     assert h2 is h and r2 is r
     with pytest.raises(Exception):
         freeu.fourier_filter(torch.zeros(1, 1, 128, 128, device="cuda"), 1, 0.5)   # > 4096 elements per plane
+
+
+def test_preprocess_properties_constant_and_saturated_images():
+    """size-independent properties: a constant image stays constant through any resize (the taps sum to
+    2^22 +- rounding and the result is clipped), black -> -1, white -> +1"""
+    from instantrestore_amd.preprocess import LanczosPreprocessor
+    pre = LanczosPreprocessor(512, torch.float32)
+    imgs = []
+    for val, (h, w) in ((0, (700, 900)), (255, (333, 512)), (128, (1500, 1100)), (37, (512, 512))):
+        imgs.append(torch.full((h, w, 3), val, dtype=torch.uint8, device="cuda"))
+    out = pre(imgs).cpu()
+    lut = (torch.arange(256, dtype=torch.float32) / 255.0 - 0.5) / 0.5
+    for i, val in enumerate((0, 255, 128, 37)):
+        assert torch.equal(out[i], torch.full((3, 512, 512), float(lut[val]))), val
+    assert float(out[0].max()) == -1.0 and float(out[1].min()) == 1.0

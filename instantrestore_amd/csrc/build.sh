@@ -14,7 +14,10 @@ mkdir -p "${BUILD_DIR}"
 for s in "${SRCS[@]}"; do
   o="${BUILD_DIR}/${s%.hip}.o"
   OBJS+=("$o")
-  "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "$@" -c "$s" -o "$o" &
+  extra=()
+  # the ping-pong kernels need scalar (single-issue) fp32 code where the SLP vectoriser would form v_pk_* operations
+  [[ "$s" == shared_attn_fwd_w64.hip ]] && extra+=(-fno-slp-vectorize)
+  "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${extra[@]}" "$@" -c "$s" -o "$o" &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done

@@ -87,6 +87,7 @@ hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hip
 hipError_t ir_launch_shared_attn_combine(const AttnKParams& p, int dtype, int qb, int rem, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s);
+hipError_t ir_launch_shared_attn_fwd_w64x8_pp(const AttnKParams& p, int dtype, hipStream_t s);
 bool ir_attn_default_is_w64(const AttnKParams& p);
 
 // Remainder split: `rem` items of the last, partially filled round (per XCD) on `slots` concurrently

@@ -407,6 +407,7 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 // variant & 15 selects the kernel (tuning hook; 0 = default dispatch, see ir_attn_default_is_w64):
 //   13 64 query rows per wave, 8-wave (512-row) workgroups (shared_attn_fwd_w64.hip; default on long axes)
 //   12 the same in 4-wave (256-row) workgroups
+//   15 13 with rotated phases and the two wave groups of a workgroup one phase apart (ping-pong; see the kernel)
 //   10 software-pipelined 32-row kernel, 4 waves, asm-issued LDS-DMA staging, lazy max (shared_attn_fwd_pipe.hip;
 //      default everywhere else)        7 the same with an exact (every-change) rescale
 //   11 10 + pre-scaled Q, reference through the MFMA C operand (opt-in fast mode: one more rounding of Q)
@@ -459,6 +460,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   if (base == 11) return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);  // + pre-scaled Q, reference through the MFMA C operand
   if (base == 12) return ir_launch_shared_attn_fwd_w64(p, dtype, s);  // 64 rows per wave
   if (base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);  // 64 rows per wave, 8-wave (512-row) workgroups
+  if (base == 15) return ir_launch_shared_attn_fwd_w64x8_pp(p, dtype, s);  // 13 with the two wave groups one phase apart
   if (base == 14) return ir_launch_shared_attn_fwd_pipe(p, dtype, 14, s);  // pipelined, QK^T of the next tile issued before the row max
   if (base == 8) return ir_launch_shared_attn_fwd_pp(p, dtype, s);  // ping-pong wave groups (shared_attn_fwd_pp.hip)
   const int nw = (base == 1) ? 8 : 4;

@@ -30,7 +30,14 @@ struct RowBlock {
 //   acc' <- acc' * (a_cur / a_next) + l_cur * (b_cur / a_next)        (a = 1, b = 0 for the self segment)
 // and at the end a_next = 1 turns the frame into the true total.  a = (sigma_style + eps) /
 // (sigma_content + eps) is strictly positive; the lazy-max rescale is linear and touches acc' as before.
-template <typename T, bool FOLD, int NW = 4>
+// PP ("ping-pong", 8 waves): the loop is rotated to { PV(t-1), QK^T(t) | barrier | softmax(t) | barrier } and waves
+// 4-7 run ONE PHASE behind waves 0-3 (one extra barrier at their start, one at the others' end), so on every SIMD
+// one wave is in its vector phase while the other is in its matrix phase - with a single barrier per tile both
+// waves of a SIMD sit in the same phase and matrix and vector time simply add up (tools/ubench/pingpong2.hip:
+// 2080 -> 1650 ns per tile pair for this instruction mix).  K/V ring of 4 pairs: pair u is read in phases
+// 2u .. 2u+3 (K(u) by QK^T(u) in M(u), V(u) by PV(u) in M(u+1), each phase twice: once per wave group); every
+// wave issues its share of pair j+2 at the start of its M(j) and waits for pair j+1 at the end of it.
+template <typename T, bool FOLD, int NW = 4, bool PP = false>
 __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
@@ -42,9 +49,14 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #ifndef W64_RING
 #define W64_RING 2
 #endif
-  constexpr int RING = W64_RING;
+  constexpr int RING = PP ? 4 : W64_RING;
   constexpr int K_OFF = 0, V_OFF = RING * TILE_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * RING * TILE_BYTES];
+  // PP: the ring (64 KiB) and a wave-private copy of the Q fragments (8 KiB per wave; the rotated loop keeps the
+  // next tile's scores alive across the iteration and has no registers left for them) exceed the static limit
+  __shared__ __attribute__((aligned(16))) unsigned char smem_static[PP ? 16 : 2 * RING * TILE_BYTES];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+  unsigned char* const smem = PP ? smem_dyn : smem_static;
+  constexpr int Q_OFF = 2 * RING * TILE_BYTES;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -198,6 +210,26 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     const float mc = R.m_run * c2;
     const f32x2 cc = {c2, c2};
     const f32x2 nm = {-mc, -mc};
+    if (PP) {
+      // single-issue forms only: packed fp32 operations share the matrix pipe's datapath and do not make
+      // progress while the other wave of the SIMD has MFMAs in flight (tools/ubench/overlap_types.hip: 6-14 %
+      // overlap against 71-97 % for v_fma_f32 / v_exp_f32 / v_cvt_pk / v_max3).  Plain scalar code: this file is
+      // built with -fno-slp-vectorize (build.sh) so that it stays scalar, and the compiler's hazard recogniser
+      // still sees the v_exp -> VALU dependency (it cannot look inside inline asm).
+      float la0 = R.la[0], la1 = R.la[1], lb0 = R.lb[0], lb1 = R.lb[1];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float x0 = fast_exp2(__builtin_fmaf(s0[r], c2, -mc));
+        const float x1 = fast_exp2(__builtin_fmaf(s0[r + 1], c2, -mc));
+        const float y0 = fast_exp2(__builtin_fmaf(s1[r], c2, -mc));
+        const float y1 = fast_exp2(__builtin_fmaf(s1[r + 1], c2, -mc));
+        la0 += x0; la1 += x1; lb0 += y0; lb1 += y1;
+        s0[r] = x0; s0[r + 1] = x1;
+        s1[r] = y0; s1[r + 1] = y1;
+      }
+      R.la = f32x2{la0, la1};
+      R.lb = f32x2{lb0, lb1};
+    } else {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       f32x2 t0v = {s0[r], s0[r + 1]};
@@ -210,6 +242,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       R.lb += t1v;
       s0[r] = t0v[0]; s0[r + 1] = t0v[1];
       s1[r] = t1v[0]; s1[r + 1] = t1v[1];
+    }
     }
     pk[0][0] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
     pk[0][1] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
@@ -262,40 +295,62 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #pragma unroll
   for (int c = 0; c < CH; ++c) { kvo[c] += (unsigned)(t0 * kstep); vvo[c] += (unsigned)(t0 * vstep); }
   issue_pair(0);
-  if (RING == 3 && NTILES > 1) issue_pair(1);
+  if ((RING == 3 || PP) && NTILES > 1) issue_pair(1);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qA[ks]), "v"(qB[ks]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  int cur = 0;
-  for (int t = 0; t < NTILES; ++t) {
-    // pair t+RING-1 goes into the slot that was last read in step t-1
-    if (t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
-
-    // ---- S^T = K Q^T for both row blocks: every K fragment is fetched once, used twice ----------
-    const unsigned char* Kb = smem + K_OFF + cur * TILE_BYTES;
-    f32x16 sa0, sa1, sb0, sb1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; }
+  if (PP) {
+    unsigned char* ql = smem + Q_OFF + wid * 8192 + lane * 16;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const v8 k0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks]);
-      const v8 k1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks]);
-      sa0 = Tr::mfma(k0, qA[ks], sa0);
-      sa1 = Tr::mfma(k1, qA[ks], sa1);
-      sb0 = Tr::mfma(k0, qB[ks], sb0);
-      sb1 = Tr::mfma(k1, qB[ks], sb1);
+      *(IR_LDS v8*)(IR_LDS unsigned char*)(ql + ks * 1024) = qA[ks];
+      *(IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + ks) * 1024) = qB[ks];
+    }
+  }
+  __syncthreads();
+
+  // S^T = K Q^T of one tile for both row blocks: every K fragment is fetched once, used twice
+  auto qk_tile = [&](const unsigned char* Kb, f32x16& sa0, f32x16& sa1, f32x16& sb0, f32x16& sb1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; }
+    if (PP) {   // Q fragments from the wave's LDS copy, one step ahead like the K fragments
+      const unsigned char* ql = smem + Q_OFF + wid * 8192 + lane * 16;
+      v8 kc0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[0]);
+      v8 kc1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[0]);
+      v8 qa = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql);
+      v8 qb = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + 4 * 1024);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        v8 kn0 = kc0, kn1 = kc1, qan = qa, qbn = qb;
+        if (ks < 3) {
+          kn0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks + 1]);
+          kn1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks + 1]);
+          qan = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (ks + 1) * 1024);
+          qbn = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + ks + 1) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        sa0 = Tr::mfma(kc0, qa, sa0);
+        sa1 = Tr::mfma(kc1, qa, sa1);
+        sb0 = Tr::mfma(kc0, qb, sb0);
+        sb1 = Tr::mfma(kc1, qb, sb1);
+        __builtin_amdgcn_sched_barrier(0);
+        kc0 = kn0; kc1 = kn1; qa = qan; qb = qbn;
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const v8 k0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks]);
+        const v8 k1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks]);
+        sa0 = Tr::mfma(k0, qA[ks], sa0);
+        sa1 = Tr::mfma(k1, qA[ks], sa1);
+        sb0 = Tr::mfma(k0, qB[ks], sb0);
+        sb1 = Tr::mfma(k1, qB[ks], sb1);
+      }
     }
     asm volatile("s_nop 7\n\ts_nop 4" : "+v"(sa0), "+v"(sa1), "+v"(sb0), "+v"(sb1));  // MFMA -> asm v_max3 pad
-
-    const int valid = c_len - ct0 * KVB;
-    v8 pkA[2][2], pkB[2][2];
-    softmax(A, sa0, sa1, pkA, valid);
-    softmax(Bk, sb0, sb1, pkB, valid);
-
-    // ---- O^T += V^T P^T for both row blocks: every V^T fragment is fetched once, used twice -----
-    const unsigned char* Vb = smem + V_OFF + cur * TILE_BYTES;
+  };
+  // O^T += V^T P^T of one tile for both row blocks: every V^T fragment is fetched once, used twice
+  auto pv_tile = [&](const unsigned char* Vb, v8 (&pkA)[2][2], v8 (&pkB)[2][2]) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -309,6 +364,64 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         Bk.o1 = Tr::mfma(v1, pkB[kb][ks], Bk.o1);
       }
     }
+  };
+
+  if (PP) {
+    // Phases of a wave: M(0) V(0) M(1) V(1) ... V(NT-1) M(NT), a barrier after each;  M(t) = PV(t-1), QK^T(t) and
+    // V(t) = softmax(t).  The scores live inside one iteration, the probabilities are carried to the next.
+    const int grp = wid >> 2;
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one phase behind
+    v8 pkA[2][2], pkB[2][2];
+    int cur = 0, prev = 3;
+    auto close_tile = [&](bool has_next) {
+      if (++ct0 == c_ntile) {
+        if (FOLD) fold_boundary(cseg, has_next);
+        ct0 = 0; ++cseg; c_ntile = p.tiles_ref; c_len = p.Lr;
+      }
+    };
+    for (int t = 0; t < NTILES; ++t) {
+      // ---- matrix phase ----------------------------------------------------------------------------
+      const bool more = t + 2 < NTILES;
+      if (more) issue_pair(cur >= 2 ? cur - 2 : cur + 2);   // pair t+2 -> the slot pair t-2 left two barriers ago
+      if (t > 0) {
+        pv_tile(smem + V_OFF + prev * TILE_BYTES, pkA, pkB);
+        close_tile(true);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the score accumulators must not come alive under PV
+      f32x16 sa0, sa1, sb0, sb1;
+      qk_tile(smem + K_OFF + cur * TILE_BYTES, sa0, sa1, sb0, sb1);
+      // pair t+1 has landed (vector memory operations retire in issue order; only pair t+2 may stay in flight)
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- vector phase ----------------------------------------------------------------------------
+      const int valid = c_len - ct0 * KVB;
+      softmax(A, sa0, sa1, pkA, valid);
+      softmax(Bk, sb0, sb1, pkB, valid);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      prev = cur;
+      cur = (cur == 3) ? 0 : cur + 1;
+    }
+    pv_tile(smem + V_OFF + prev * TILE_BYTES, pkA, pkB);
+    close_tile(false);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
+  int cur = 0;
+  for (int t = 0; t < NTILES; ++t) {
+    // pair t+RING-1 goes into the slot that was last read in step t-1
+    if (t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
+
+    const unsigned char* Kb = smem + K_OFF + cur * TILE_BYTES;
+    f32x16 sa0, sa1, sb0, sb1;
+    qk_tile(Kb, sa0, sa1, sb0, sb1);
+
+    const int valid = c_len - ct0 * KVB;
+    v8 pkA[2][2], pkB[2][2];
+    softmax(A, sa0, sa1, pkA, valid);
+    softmax(Bk, sb0, sb1, pkB, valid);
+
+    pv_tile(smem + V_OFF + cur * TILE_BYTES, pkA, pkB);
     if (++ct0 == c_ntile) {
       if (FOLD) fold_boundary(cseg, t + 1 < NTILES);
       ct0 = 0; ++cseg; c_ntile = p.tiles_ref; c_len = p.Lr;
@@ -320,6 +433,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur = (RING == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
+  }
   }
 
   // ---- epilogue (per row block) ---------------------------------------------------------------------
@@ -369,7 +483,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   finish(Bk, qrowB, 32);
 }
 
-template <typename T, bool FOLD, int NW = 4>
+template <typename T, bool FOLD, int NW = 4, bool PP = false>
 hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   AttnKParams p = p0;
   constexpr int QB = NW * 64;
@@ -390,7 +504,18 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.ws_o = p.ws;
   p.ws_ml = p.ws + (size_t)8 * rem * k * QB * 64;
   const int grid = 8 * (full + rem * k);
-  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW>), dim3(grid), dim3(NW * 64), 0, s, p);
+  size_t dyn_lds = 0;
+  if (PP) {
+    dyn_lds = (size_t)2 * 4 * TILE_BYTES + (size_t)NW * 8192;   // ring of 4 K/V pairs + the waves' Q fragments
+    static bool attr_set = false;   // per instantiation; idempotent, so a race only repeats the call
+    if (!attr_set) {
+      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, PP>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+      if (ea != hipSuccess) return ea;
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, PP>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || k <= 1) return e;
   return ir_launch_shared_attn_combine(p, std::is_same<T, __bf16>::value ? 1 : 0, QB, rem, s);
@@ -398,9 +523,18 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
 
 }  // namespace
 
+template <bool PP>
+static hipError_t launch_x8(const AttnKParams& p, int dtype, hipStream_t s) {
+  if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8, PP>(p, s) : launch<_Float16, true, 8, PP>(p, s);
+  return dtype == 1 ? launch<__bf16, false, 8, PP>(p, s) : launch<_Float16, false, 8, PP>(p, s);
+}
+
+hipError_t ir_launch_shared_attn_fwd_w64x8_pp(const AttnKParams& p, int dtype, hipStream_t s) {  // ping-pong wave groups
+  return launch_x8<true>(p, dtype, s);
+}
+
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s) {  // 8-wave (512-row) workgroups
-  if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8>(p, s) : launch<_Float16, true, 8>(p, s);
-  return dtype == 1 ? launch<__bf16, false, 8>(p, s) : launch<_Float16, false, 8>(p, s);
+  return launch_x8<false>(p, dtype, s);
 }
 
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s) {

@@ -161,7 +161,8 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         "traffic": _pmc_traffic_bytes() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
         "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_shared_attn.txt)",
         "power_note": "this kernel runs at the 1400 W board cap on random data (profiles/r1_power_probe.txt): "
-                      "sustained shader clock 2.1-2.2 GHz against the 2.4 GHz the peak assumes",
+                      "sustained shader clock 2.1-2.2 GHz against the 2.4 GHz the peak assumes; an MFMA-only stream of the same "
+                      "instruction holds 1.96 PFLOP/s on random operands under that cap (profiles/r1_ubench_mfma_power.txt)",
     }
 
 

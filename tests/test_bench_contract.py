@@ -38,3 +38,26 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "shared_attn" in rf["kernel"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """The N = 2 launch exactly as the driver issues it (torch.distributed.run, one process per rank), with the
+    test hooks that put both ranks on cuda:0 and run the two control-plane collectives over gloo: rank 0 prints the
+    one line, n_gpus = 2, the whole-job value counts both ranks' identities over the MAX of the ranks' times."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, IR_BENCH_DIST_BACKEND="gloo", IR_BENCH_SHARE_DEVICE="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline"],
+                       capture_output=True, text=True, cwd=REPO, timeout=900, env=env)
+    assert r.returncode == 0, (r.stderr + r.stdout)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
+    assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    assert d["cpu_baseline"] is None and d["config"]["parallelism"].startswith("dp2")

@@ -175,8 +175,9 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   int c_ntile = first_is_self ? p.tiles_self : p.tiles_ref;
   int c_len = first_is_self ? p.Ls : p.Lr;
 
-  // softmax step of one row block on (s0, s1) -> pk
-  auto softmax = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], int valid) {
+  // softmax step of one row block on (s0, s1) -> pk, in two parts: the row max of the tile (masking ragged keys
+  // first), then rescale check, exponentials, row sums and the 16-bit probabilities
+  auto row_max = [&](f32x16& s0, f32x16& s1, int valid) -> float {
     if (valid < KVB) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -193,10 +194,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       mxb = max3(mxb, s1[r], s1[r + 1]);
     }
     float mx = max3(mxa, mxb, max3(s0[15], s1[15], s1[15]));
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), mx);
-    }
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    return max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), mx);
+  };
+  auto softmax_rest = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], float mx) {
     if (__any(mx > R.m_run + lazy_thr)) {  // lazy max: keep the reference while P stays <= 2^6
       const float m_new = max3(R.m_run, mx, mx);
       const float alpha = fast_exp2((R.m_run - m_new) * c2);
@@ -248,6 +249,11 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     pk[0][1] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
     pk[1][0] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
     pk[1][1] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+  };
+
+  auto softmax = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], int valid) {
+    const float mx = row_max(s0, s1, valid);
+    softmax_rest(R, s0, s1, pk, mx);
   };
 
   // FOLD: close segment `sc`; `has_next`: another (reference) segment follows in this piece
@@ -366,6 +372,14 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     }
   };
 
+#ifdef W64_PP_TRACE
+  // development aid: waves 0 and 4 of workgroup 0 stamp s_memtime at the phase boundaries of tiles 8..23 into the
+  // head of the LSE buffer (rows of a whole item: the combine kernel does not write there) (the normal LSE stores are compiled out in this build)
+#define PP_STAMP(ev) do { if (blockIdx.x == 0 && (wid == 0 || wid == 4) && t >= 8 && t < 24 && lane == 0 && p.lse != nullptr) \
+    p.lse[((wid >> 2) * 16 + (t - 8)) * 8 + (ev)] = __uint_as_float((unsigned)__builtin_readcyclecounter()); } while (0)
+#else
+#define PP_STAMP(ev) do { } while (0)
+#endif
   if (PP) {
     // Phases of a wave: M(0) V(0) M(1) V(1) ... V(NT-1) M(NT), a barrier after each;  M(t) = PV(t-1), QK^T(t) and
     // V(t) = softmax(t).  The scores live inside one iteration, the probabilities are carried to the next.
@@ -381,25 +395,41 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     };
     for (int t = 0; t < NTILES; ++t) {
       // ---- matrix phase ----------------------------------------------------------------------------
+      PP_STAMP(0);
+      __builtin_amdgcn_s_setprio(3);   // the matrix phase wins the issue port: both phases then take the same time (tools/gpu_pp_trace.py)
       const bool more = t + 2 < NTILES;
       if (more) issue_pair(cur >= 2 ? cur - 2 : cur + 2);   // pair t+2 -> the slot pair t-2 left two barriers ago
       if (t > 0) {
         pv_tile(smem + V_OFF + prev * TILE_BYTES, pkA, pkB);
         close_tile(true);
       }
+      PP_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);   // the score accumulators must not come alive under PV
       f32x16 sa0, sa1, sb0, sb1;
       qk_tile(smem + K_OFF + cur * TILE_BYTES, sa0, sa1, sb0, sb1);
       // pair t+1 has landed (vector memory operations retire in issue order; only pair t+2 may stay in flight)
       if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_STAMP(2);
       __builtin_amdgcn_s_barrier();
-      // ---- vector phase ----------------------------------------------------------------------------
+      PP_STAMP(3);
+      __builtin_amdgcn_s_setprio(0);
+      // ---- vector phase (row max included: moved into the matrix phase it lengthens the critical wave by more
+      //      than it saves here - tools/gpu_pp_trace.py) -----------------------------------------------------
       const int valid = c_len - ct0 * KVB;
       softmax(A, sa0, sa1, pkA, valid);
       softmax(Bk, sb0, sb1, pkB, valid);
+      // the probabilities are used in the NEXT phase only: without these pins hipcc sinks the exp / convert half of
+      // the softmax and the row-sum additions below the barrier, i.e. into the matrix phase
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(pkA[i][j]), "+v"(pkB[i][j]));
+      asm volatile("" : "+v"(A.la), "+v"(A.lb), "+v"(Bk.la), "+v"(Bk.lb));   // the row sums too (next use: segment end)
       __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP(4);
       __builtin_amdgcn_s_barrier();
+      PP_STAMP(5);
       prev = cur;
       cur = (cur == 3) ? 0 : cur + 1;
     }
@@ -475,8 +505,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
         *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
       }
+#ifndef W64_PP_TRACE
       if (p.lse != nullptr && hi == 0)
         p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = R.m_run * p.scale + __logf(l_fin);
+#endif
     }
   };
   finish(A, qrowA, 0);

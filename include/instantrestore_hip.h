@@ -256,8 +256,9 @@ int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32
  *
  * Replaces attn.to_q/to_k/to_v and attn.to_out[0] (nn.Linear; attn_processors.py:222-230,267) for
  * in_features K in {64, 128, ..., 320}: X-stationary MFMA kernel, W streamed through LDS, fp32
- * accumulation, one rounding to the 16-bit dtype (bias added in fp32 before it).  Other K return
- * IR_ERR_UNSUPPORTED and the caller keeps the vendor GEMM.
+ * accumulation, one rounding to the 16-bit dtype (bias added in fp32 before it); and for K = 640 (the
+ * 32x32-token layer class) the same with the contraction split over two waves whose fp32 partial tiles
+ * meet in LDS.  Other K return IR_ERR_UNSUPPORTED and the caller keeps the vendor GEMM.
  *   x (M, K) rows x_ld elements apart; w (N, K) rows w_ld apart (torch Linear weight layout);
  *   bias (N) or NULL; y (M, N) rows y_ld apart; N % 32 == 0; all ld % 8 == 0, pointers 16-B aligned
  */

@@ -105,8 +105,8 @@ _SKINNY_MIN_WORK = 1 << 24   # rows * out_features below which the vendor GEMM i
 
 
 def _linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """``F.linear`` with the K <= 320 shapes of the 64x64-token layer class routed to the
-    X-stationary HIP GEMM (``ir_linear_fwd``, 1.5x the vendor kernel there); every other shape is a
+    """``F.linear`` with the large K <= 320 and K = 640 shapes (64x64- and 32x32-token layer classes) routed
+    to the X-stationary HIP GEMM (``ir_linear_fwd``, 1.5-1.6x the vendor kernel there); every other shape is a
     plain library GEMM and stays one."""
     rows = x.numel() // x.shape[-1]
     if rows * w.shape[0] >= _SKINNY_MIN_WORK and _ops.linear_supported(x, w, bias):

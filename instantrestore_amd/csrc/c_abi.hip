@@ -347,7 +347,7 @@ int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x,
   if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d: fp16 (0) / bf16 (1)", dtype);
   if (!x || !w || !y) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
   if (m <= 0 || n <= 0 || k <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
-  if (k % 64 != 0 || k > 320) return fail(IR_ERR_UNSUPPORTED, "K = %d: this kernel covers K in {64,...,320}", k);
+  if ((k % 64 != 0 || k > 320) && k != 640) return fail(IR_ERR_UNSUPPORTED, "K = %d: this kernel covers K in {64,...,320} and 640", k);
   if (n % 32 != 0) return fail(IR_ERR_UNSUPPORTED, "N = %d must be a multiple of 32", n);
   if (bias != nullptr && n > kLinearMaxBiasN) return fail(IR_ERR_UNSUPPORTED, "N = %d with bias: at most %d", n, kLinearMaxBiasN);
   if (m > 0x7fffffffLL - 256) return fail(IR_ERR_UNSUPPORTED, "M too large");

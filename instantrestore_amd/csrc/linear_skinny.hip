@@ -168,11 +168,217 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   store_chunk(accA, accB, (c_end - 1) * NCH);
 }
 
+// K = 640 (the 32x32-token layer class): 64 rows of X no longer fit one wave's registers, so the contraction
+// is split across TWO waves of the workgroup.  8 waves: wave w owns row block (w & 3) and K half (w >> 2), keeps
+// its 64 x 320 slice of X in registers exactly like the kernel above and streams the same W chunks (32 columns x
+// all of K, one LDS image for all eight waves).  After a chunk the upper-half waves leave their fp32 partial
+// tile in LDS (lane-linear, 8 KiB per row block, two chunk parities); the lower-half waves pick it up after the
+// chunk barrier, add, and reuse that very LDS region as the staging tile of their transposed stores, which
+// again ride between the MFMAs of the next chunk.  LDS: 2 x 40 KiB of W + 64 KiB of partials (+ bias).
+template <typename T, int KSH>               // K = 128 * KSH
+__global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKParams p) {
+  using Tr = ElemTraits<T>;
+  using v8 = typename Tr::v8;
+  using v4 = typename Tr::v4;
+  constexpr int KS2 = 2 * KSH;
+  constexpr int CHUNK_BYTES = KS2 * SUB_BYTES;
+  constexpr int R_OFF = 2 * CHUNK_BYTES;     // partial tiles: [parity][row block] x 8 KiB
+  constexpr int TPITCH = 80;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  unsigned char* const smem = dsm;
+  __shared__ __attribute__((aligned(16))) T sbias[kLinearMaxBiasN];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rb = wid & 3, kh = wid >> 2;
+  const int hi = lane >> 5, lq = lane & 31;
+
+  const int mb = blockIdx.x / p.nsplit, sp = blockIdx.x - mb * p.nsplit;
+  const int nchunks = p.N / NCH;
+  const int c_begin = (int)(((long)nchunks * sp) / p.nsplit), c_end = (int)(((long)nchunks * (sp + 1)) / p.nsplit);
+  if (c_begin >= c_end) return;
+
+  // ---- this wave's half of the X rows: resident for the whole kernel -------------------------------
+  const int rowA = mb * 256 + rb * 64 + lq, rowB = rowA + 32;
+  v8 xA[4 * KSH], xB[4 * KSH];
+  {
+    const int ra = rowA < p.M ? rowA : p.M - 1, rb2 = rowB < p.M ? rowB : p.M - 1;
+    const T* base = (const T*)p.x + kh * (64 * KSH) + hi * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4 * KSH; ++ks) {
+      xA[ks] = *(const v8*)(base + (int64_t)ra * p.x_ld + ks * 16);
+      xB[ks] = *(const v8*)(base + (int64_t)rb2 * p.x_ld + ks * 16);
+    }
+  }
+
+  // ---- W chunk stream: sub-tile s = 2 i + (tid >> 8), 16 B per thread, lane-linear LDS image -----------
+  const int t2 = tid & 255, half = wid >> 2;   // wave-uniform: the LDS destination of a transfer lives in M0
+  const int wrow = t2 >> 3, wslot = t2 & 7;
+  const i32x4 wrw = make_rsrc_words(p.w, (unsigned)(((int64_t)(p.N - 1) * p.w_ld + 128 * KSH) * 2));
+  const unsigned wvo = (unsigned)(wrow * p.w_ld * 2 + ((wslot ^ ((wrow >> 1) & 7)) * 16));
+  auto issue_chunk = [&](int c, int slot) {
+    const unsigned off = wvo + (unsigned)((int64_t)c * NCH * p.w_ld * 2);
+#pragma unroll
+    for (int i = 0; i < KSH; ++i) {
+      const int s = 2 * i + half;
+      buffer_load_lds16_async(wrw, smem + slot * CHUNK_BYTES + s * SUB_BYTES + (wid & 3) * 1024, off + s * 128);
+    }
+  };
+  int wread[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) wread[ks] = lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4);
+
+  if (p.bias != nullptr)
+    for (int i = tid; i < (c_end - c_begin) * NCH; i += 512) sbias[i] = ((const T*)p.bias)[c_begin * NCH + i];
+  const int ncl = c_end - c_begin;
+  issue_chunk(c_begin, 0);
+#pragma unroll
+  for (int ks = 0; ks < 4 * KSH; ++ks) asm volatile("" ::"v"(xA[ks]), "v"(xB[ks]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto rtile = [&](int par) { return smem + R_OFF + (par * 4 + rb) * 8192; };
+  // upper half: leave the partial tile (2 x 16 fp32 per lane) lane-linear in LDS
+  auto put_partial = [&](const f32x16& a, const f32x16& b, int par) {
+    unsigned char* r = rtile(par) + lane * 16;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 fa, fb;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { fa[i] = a[4 * g + i]; fb[i] = b[4 * g + i]; }
+      *(IR_LDS f32x4*)(IR_LDS unsigned char*)(r + g * 1024) = fa;
+      *(IR_LDS f32x4*)(IR_LDS unsigned char*)(r + (4 + g) * 1024) = fb;
+    }
+  };
+  // lower half: add the partner's partial, add the bias, round, and stage the 64 x 32 tile for the transposed stores
+  // in the same LDS region (this wave's reads of it are complete before its writes: LDS operations of a wave execute in order)
+  auto finish_tile = [&](f32x16& a, f32x16& b, int par, int n0) {
+    unsigned char* r = rtile(par);
+    auto rd = [&](int q) { return *(const IR_LDS f32x4*)(IR_LDS unsigned char*)(r + lane * 16 + q * 1024); };
+    auto bias4 = [&](int g) {
+      f32x4 f = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) {
+        const v4 bv = *(const v4*)(sbias + (n0 - c_begin * NCH) + 8 * g + 4 * hi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (float)bv[i];
+      }
+      return f;
+    };
+    // the staged rows of block A (bytes 0 .. 2559 of the tile) cover the partial quads 0-2 of A; those of block B
+    // (2560 .. 5119) cover A's quad 3 and B's quad 0 (4096 ..): read what a write is about to cover first
+    f32x4 pa[4], pb0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pa[g] = rd(g);
+    pb0 = rd(4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bz = bias4(g);
+      f32x4 fa;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = a[4 * g + i] + pa[g][i] + bz[i];
+      *(v4*)(r + lq * TPITCH + (8 * g + 4 * hi) * 2) = __builtin_convertvector(fa, v4);
+    }
+    f32x4 pb[4];
+    pb[0] = pb0;
+#pragma unroll
+    for (int g = 1; g < 4; ++g) pb[g] = rd(4 + g);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 bz = bias4(g);
+      f32x4 fb;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fb[i] = b[4 * g + i] + pb[g][i] + bz[i];
+      *(v4*)(r + (32 + lq) * TPITCH + (8 * g + 4 * hi) * 2) = __builtin_convertvector(fb, v4);
+    }
+  };
+  const int row0 = mb * 256 + rb * 64;
+  auto store_part = [&](int j, int par, int n0) {   // 16 rows x 64 B of the staged tile
+    const int rr = 16 * j + (lane >> 2);
+    const u32x4 v = *(const u32x4*)(rtile(par) + rr * TPITCH + (lane & 3) * 16);
+    const int row = row0 + rr;
+    T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 3) * 8;
+    *(u32x4*)yp = v;
+  };
+
+  f32x16 accA, accB;
+  for (int i = 0; i < ncl; ++i) {
+    const int c = c_begin + i, cur = i & 1;
+    if (i + 1 < ncl) issue_chunk(c + 1, cur ^ 1);
+    const bool fin = (kh == 0) && (i > 0);   // chunk i-1 is finished by the lower-half wave while it computes chunk i
+    if (fin) finish_tile(accA, accB, (i - 1) & 1, (c - 1) * NCH);
+    const unsigned char* Wb = smem + cur * CHUNK_BYTES + kh * KSH * SUB_BYTES;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+    // W fragments one half sub-tile ahead: the two reads of the next group are in flight under four MFMAs (a full
+    // double buffer costs 16 registers this kernel does not have)
+    v8 wa[2], wb[2];
+    wa[0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Wb + wread[0]);
+    wa[1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Wb + wread[1]);
+#pragma unroll
+    for (int s = 0; s < KSH; ++s) {
+      wb[0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Wb + s * SUB_BYTES + wread[2]);
+      wb[1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Wb + s * SUB_BYTES + wread[3]);
+      __builtin_amdgcn_sched_barrier(0);
+      accA = Tr::mfma(wa[0], xA[4 * s + 0], accA);
+      accB = Tr::mfma(wa[0], xB[4 * s + 0], accB);
+      accA = Tr::mfma(wa[1], xA[4 * s + 1], accA);
+      accB = Tr::mfma(wa[1], xB[4 * s + 1], accB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 1 < KSH) {
+        wa[0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Wb + (s + 1) * SUB_BYTES + wread[0]);
+        wa[1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Wb + (s + 1) * SUB_BYTES + wread[1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      accA = Tr::mfma(wb[0], xA[4 * s + 2], accA);
+      accB = Tr::mfma(wb[0], xB[4 * s + 2], accB);
+      accA = Tr::mfma(wb[1], xA[4 * s + 3], accA);
+      accB = Tr::mfma(wb[1], xB[4 * s + 3], accB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (fin) {
+        if (s < 4) store_part(s, (i - 1) & 1, (c - 1) * NCH);
+        if (s == KSH - 1) {
+#pragma unroll
+          for (int j = KSH; j < 4; ++j) store_part(j, (i - 1) & 1, (c - 1) * NCH);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kh == 1) put_partial(accA, accB, i & 1);
+    // the next chunk has landed: the four stores of a finishing wave were issued after its transfers and may stay in flight
+    if (fin) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  if (kh == 0) {
+    const int n0 = (c_end - 1) * NCH, par = (ncl - 1) & 1;
+    finish_tile(accA, accB, par, n0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) store_part(j, par, n0);
+  }
+}
+
 template <typename T>
 hipError_t launch(const LinearKParams& p0, hipStream_t s) {
   LinearKParams p = p0;
   const int mblocks = (p.M + 255) / 256;
   const int nchunks = p.N / NCH;
+  if (p.K == 640) {   // contraction split over two waves, one 8-wave workgroup per CU
+    int nsplit = (256 + mblocks - 1) / mblocks;
+    if (nsplit > nchunks) nsplit = nchunks;
+    if (nsplit < 1) nsplit = 1;
+    p.nsplit = nsplit;
+    constexpr int KSH = 5;
+    const size_t dyn = (size_t)2 * (2 * KSH) * SUB_BYTES + 2 * 4 * 8192;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t ea = hipFuncSetAttribute((const void*)linear_ksplit_kernel<T, KSH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      if (ea != hipSuccess) return ea;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((linear_ksplit_kernel<T, KSH>), dim3((unsigned)(mblocks * nsplit)), dim3(512), dyn, s, p);
+    return hipGetLastError();
+  }
   int nsplit = (512 + mblocks - 1) / mblocks;       // two workgroups per CU
   if (nsplit > nchunks) nsplit = nchunks;
   if (nsplit < 1) nsplit = 1;

@@ -344,21 +344,22 @@ def tensor2im_u8(x: torch.Tensor) -> torch.Tensor:
     return out[0] if squeeze else out
 
 
-LINEAR_MAX_K = 320   # ir_linear_fwd: in_features in {64, ..., 320}; everything else is the vendor GEMM's
+LINEAR_MAX_K = 320   # ir_linear_fwd: in_features in {64, ..., 320} and 640; everything else is the vendor GEMM's
+LINEAR_SPLIT_K = (640,)
 
 
 def linear_supported(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
     """shapes / layouts ``ir_linear_fwd`` implements (the caller keeps ``F.linear`` otherwise)"""
     n, k = weight.shape
     return (x.is_cuda and x.dtype in _DT and weight.dtype == x.dtype and x.shape[-1] == k
-            and k % 64 == 0 and k <= LINEAR_MAX_K and n % 32 == 0 and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
+            and ((k % 64 == 0 and k <= LINEAR_MAX_K) or k in LINEAR_SPLIT_K) and n % 32 == 0 and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
             and (bias is None or (bias.dtype == x.dtype and bias.is_contiguous() and n <= 4096))
             and x.numel() > 0)
 
 
 @_on_tensor_device
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``F.linear(x, weight, bias)`` for 16-bit ``x (..., K)``, ``weight (N, K)`` with K <= 320
+    """``F.linear(x, weight, bias)`` for 16-bit ``x (..., K)``, ``weight (N, K)`` with K <= 320 or K = 640
     (``ir_linear_fwd``): fp32 accumulation, one rounding.  Raises for unsupported shapes."""
     _need_gpu(x, weight, bias)
     _forward_only(x, weight, bias)

@@ -1,4 +1,4 @@
-"""GPU parity of ir_linear_fwd (the K <= 320 projection GEMM) against a float64 matmul of the same
+"""GPU parity of ir_linear_fwd (the K <= 320 projection GEMM and its K = 640 split-contraction form) against a float64 matmul of the same
 16-bit inputs.  Tolerance (floating point): fp32 accumulation + one rounding to the 16-bit output:
 |err| <= 2^-10 (fp16) / 2^-7 (bf16) relative to max(1, |y|) - half an output ulp plus slack for the
 accumulation order."""
@@ -15,6 +15,9 @@ TOL = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}
 @pytest.mark.parametrize("M,N,K,bias", [
     (256, 32, 64, False), (300, 96, 128, True), (1000, 960, 320, False), (4096, 320, 320, True),
     (33, 64, 320, True), (1, 32, 64, False), (8192, 960, 320, False), (777, 1920, 256, True), (512, 3840, 192, False),
+    # K = 640: the contraction split over two waves (partials meet in LDS)
+    (256, 32, 640, False), (300, 96, 640, True), (1, 64, 640, True), (8192, 1920, 640, False), (8192, 640, 640, True),
+    (2049, 704, 640, True), (32768, 640, 640, True),
 ])
 def test_linear_matches_float64(dtype, M, N, K, bias):
     from instantrestore_amd import ops
@@ -49,12 +52,17 @@ def test_linear_exact_column_order_and_strided_input():
     wbig = torch.randint(-2, 3, (3 * 96, 320), generator=g).to(torch.bfloat16).cuda()
     y2 = ops.linear(x.cuda(), wbig[96:192]).cpu()
     assert torch.equal(y2.float(), (x.float() @ wbig[96:192].cpu().float().T).to(torch.bfloat16).float())
+    # the same with K = 640 (two K halves in two waves: a swapped or dropped half is an exact mismatch)
+    x6 = torch.randint(-3, 4, (2, 130, 640), generator=g).to(torch.bfloat16)
+    w6 = torch.randint(-2, 3, (96, 640), generator=g).to(torch.bfloat16)
+    y6 = ops.linear(x6.cuda(), w6.cuda(), b.cuda()).cpu()
+    assert torch.equal(y6.float(), (x6.float() @ w6.float().T + b.float()).to(torch.bfloat16).float())
 
 
 def test_linear_rejects_what_it_does_not_implement():
     from instantrestore_amd import _lib, ops
-    x = torch.zeros(64, 640, device="cuda", dtype=torch.bfloat16)
-    w = torch.zeros(64, 640, device="cuda", dtype=torch.bfloat16)
+    x = torch.zeros(64, 1280, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(64, 1280, device="cuda", dtype=torch.bfloat16)
     assert not ops.linear_supported(x, w, None)
     with pytest.raises(_lib.IRError):
         ops.linear(x, w)
@@ -76,4 +84,14 @@ def test_linear_stress_full_size_against_vendor_gemm():
         y, ref = ops.linear(x, w), torch.nn.functional.linear(x, w)
         assert (y.float() - ref.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref.float().abs().max().item()), it
         y2, ref2 = ops.linear(x, wo, bo), torch.nn.functional.linear(x, wo, bo)
+        assert (y2.float() - ref2.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref2.float().abs().max().item()), it
+    # the K = 640 form: partial tiles and staged stores share LDS regions across chunk parities
+    w6 = (torch.randn(1920, 640, device="cuda") / 25.0).to(torch.bfloat16)
+    wo6 = (torch.randn(640, 640, device="cuda") / 25.0).to(torch.bfloat16)
+    bo6 = torch.randn(640, device="cuda").to(torch.bfloat16)
+    for it in range(12):
+        x = torch.randn(32768 - 37 * it, 640, device="cuda").to(torch.bfloat16)
+        y, ref = ops.linear(x, w6), torch.nn.functional.linear(x, w6)
+        assert (y.float() - ref.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref.float().abs().max().item()), it
+        y2, ref2 = ops.linear(x, wo6, bo6), torch.nn.functional.linear(x, wo6, bo6)
         assert (y2.float() - ref2.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref2.float().abs().max().item()), it

@@ -41,3 +41,16 @@ for sets, tag in ((32, "refs"), (8, "ident"), (128, "refs 1024px")):
         fl = 2.0 * M * N * 320; by = 2.0 * (M * 320 + N * 320 + M * N)
         ideal = max(fl / 2.5e15, by / 6.3e12) * 1e3
         print(f"ir_linear {name:4s} {tag:11s} M={M:6d} N={N:4d}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TF/s {by/ms/1e6:7.1f} GB/s ({ideal/ms*100:4.1f}% of roofline) | vendor {ms_lib*1e3:7.1f} us")
+
+# the K = 640 shapes through ir_linear_fwd's split-contraction form
+for sets, tag in ((32, "refs"), (8, "ident"), (128, "refs 1024px")):
+    M = sets * 1024
+    x = torch.randn(M, 640, device="cuda", dtype=torch.bfloat16)
+    for N, bias, name in ((1920, False, "qkv"), (640, True, "out")):
+        w = torch.randn(N, 640, device="cuda", dtype=torch.bfloat16)
+        b = torch.randn(N, device="cuda", dtype=torch.bfloat16) if bias else None
+        ms = timeit(lambda: ops.linear(x, w, b))
+        ms_lib = timeit(lambda: F.linear(x, w, b))
+        fl = 2.0 * M * N * 640
+        print(f"ir_linear K=640 {name:4s} {tag:11s} M={M:6d} N={N:4d}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TF/s | vendor {ms_lib*1e3:7.1f} us")
+

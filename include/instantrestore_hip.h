@@ -13,7 +13,8 @@
  *     calling thread;
  *   - all device work is enqueued asynchronously on `stream` (a hipStream_t; NULL = the
  *     legacy default stream); nothing synchronises, nothing allocates;
- *   - the caller owns every buffer; the library keeps no state between calls;
+ *   - the caller owns every buffer; the library keeps no state between calls (no process-wide
+ *     switches: kernel selection for benchmarks is the per-call `tuning` field of the args);
  *   - tensors are described by a base pointer plus strides IN ELEMENTS; the innermost
  *     (head_dim) axis is always contiguous and head_dim is always IR_HEAD_DIM = 64
  *     (SD-Turbo: attention_head_dim [5,10,20,20] x 64 channels);
@@ -30,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IR_ABI_VERSION 3
+#define IR_ABI_VERSION 4
 #define IR_HEAD_DIM 64
 
 typedef enum ir_status {
@@ -45,6 +46,12 @@ typedef enum ir_dtype { IR_DTYPE_F16 = 0, IR_DTYPE_BF16 = 1 } ir_dtype;
 
 /* flags of ir_shared_attn_args.flags */
 #define IR_FLAG_INCLUDE_SELF 1u /* train_input: self K/V block precedes the reference blocks */
+#define IR_FLAG_Q_PRESCALED 2u  /* q already holds Q * scale * log2(e) (the fused q/k/v projection applies the factor to its
+                                   fp32 accumulator before the one rounding to 16 bit, ir_linear_fwd col_scale): the
+                                   scores leave the matrix pipe in the exp2 domain and the kernel saves one multiply-add
+                                   per score.  `scale` is still the reference's attn.scale (used for the LSE). */
+#define IR_FLAG_OUT_F32 4u      /* out is fp32 (strides in fp32 elements): the kernel's result BEFORE the rounding to the
+                                   16-bit type - parity instrumentation (tests show the pre-rounding error) */
 
 /*
  * ir_shared_attn_fwd - fused extended self-attention (flash-style, no probability matrix).
@@ -100,7 +107,20 @@ typedef struct ir_shared_attn_args {
   int64_t o_sb, o_sl, o_sh;
   void* workspace;          /* optional device scratch (see ir_shared_attn_workspace_bytes), or NULL */
   uint64_t workspace_bytes;
+  int32_t tuning;           /* 0 = default kernel dispatch.  Benchmarks / A-B tests only: IR_TUNE_* selects one kernel
+                               for this call (an unknown or unavailable value is IR_ERR_UNSUPPORTED). */
+  int32_t reserved;         /* must be 0 */
 } ir_shared_attn_args;
+
+/* values of ir_shared_attn_args.tuning (csrc/shared_attn_fwd.hip lists what each one is) */
+#define IR_TUNE_DEFAULT 0
+#define IR_TUNE_PIPE32_EXACTMAX 7
+#define IR_TUNE_PIPE32 10
+#define IR_TUNE_PIPE32_PRESCALE_Q 11
+#define IR_TUNE_W64X4 12
+#define IR_TUNE_W64X8 13
+#define IR_TUNE_PIPE32_EARLYQK 14
+#define IR_TUNE_SP64 16
 
 /*
  * Scratch for the remainder split: when the number of (batch, head, query-block) work items is not
@@ -111,7 +131,7 @@ typedef struct ir_shared_attn_args {
  */
 size_t ir_shared_attn_workspace_bytes(void);
 
-/* Name of the kernel ir_shared_attn_fwd would launch for these arguments under the current variant
+/* Name of the kernel ir_shared_attn_fwd would launch for these arguments (incl. their `tuning` field)
  * (reporting only: bench.py's roofline block); "" if the arguments are invalid. Static storage. */
 const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args);
 
@@ -269,12 +289,6 @@ int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x,
 int ir_abi_version(void);                  /* == IR_ABI_VERSION */
 const char* ir_build_info(void);           /* "gfx950 hipcc ... <date>" */
 const char* ir_last_error_string(void);    /* thread-local, never NULL */
-
-/*
- * Tuning hook (benchmarks / tests only): selects a kernel variant for subsequent
- * ir_shared_attn_fwd calls of this process. 0 = default. Returns the previous value.
- */
-int ir_set_attn_variant(int variant);
 
 /*
  * ir_time_shared_attn_fwd - launch ir_shared_attn_fwd `iters` times on `stream` bracketed by

@@ -13,10 +13,10 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # IR_LIB_PATH: load an alternative build of the same ABI (compiler-flag A/B experiments)
 LIB_PATH = os.environ.get("IR_LIB_PATH") or os.path.join(_HERE, "libinstantrestore_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 IR_DTYPE_F16, IR_DTYPE_BF16 = 0, 1
-IR_FLAG_INCLUDE_SELF = 1
+IR_FLAG_INCLUDE_SELF, IR_FLAG_Q_PRESCALED, IR_FLAG_OUT_F32 = 1, 2, 4
 
 i32, i64, f32, u32, vp = C.c_int32, C.c_int64, C.c_float, C.c_uint32, C.c_void_p
 
@@ -31,7 +31,7 @@ class SharedAttnArgs(C.Structure):
         + [(n, i64) for n in ("q_sb", "q_sl", "q_sh", "ks_sb", "ks_sl", "ks_sh", "vs_sb", "vs_sl", "vs_sh",
                               "kr_sb", "kr_sn", "kr_sl", "kr_sh", "vr_sb", "vr_sn", "vr_sl", "vr_sh",
                               "o_sb", "o_sl", "o_sh")]
-        + [("workspace", vp), ("workspace_bytes", C.c_uint64)]
+        + [("workspace", vp), ("workspace_bytes", C.c_uint64), ("tuning", i32), ("reserved", i32)]
     )
 
 
@@ -49,7 +49,6 @@ SYMBOLS = {
     "ir_abi_version": (C.c_int, []),
     "ir_build_info": (C.c_char_p, []),
     "ir_last_error_string": (C.c_char_p, []),
-    "ir_set_attn_variant": (C.c_int, [C.c_int]),
     "ir_shared_attn_workspace_bytes": (C.c_size_t, []),
     "ir_shared_attn_fwd": (C.c_int, [C.POINTER(SharedAttnArgs), vp]),
     "ir_shared_attn_kernel_name": (C.c_char_p, [C.POINTER(SharedAttnArgs)]),
@@ -102,11 +101,6 @@ def lib() -> C.CDLL:
         got = handle.ir_abi_version()
         if got != ABI_VERSION:
             raise ImportError(f"{LIB_PATH}: ABI version {got}, expected {ABI_VERSION}; rebuild")
-        # IR_ATTN_VARIANT=<n>: process-wide kernel variant without touching code (ir_set_attn_variant); e.g.
-        # 11 = "prescaled Q" fast mode (+6 % attention throughput, one extra 16-bit rounding of Q)
-        var = os.environ.get("IR_ATTN_VARIANT")
-        if var:
-            handle.ir_set_attn_variant(int(var))
         _lib = handle
     return _lib
 

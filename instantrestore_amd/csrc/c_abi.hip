@@ -1,11 +1,9 @@
 // c_abi.hip - the extern "C" surface declared in include/instantrestore_hip.h.
 // Argument validation, parameter-block construction, launches. No exceptions, no global state
-// other than a thread-local error string and the process-wide tuning variant.
+// other than a thread-local error string.
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
-
-#include <atomic>
 
 #include "../../include/instantrestore_hip.h"
 #include "ir_kernels.h"
@@ -13,7 +11,6 @@
 namespace {
 
 thread_local char g_err[512] = "";
-std::atomic<int> g_variant{0};
 
 int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -35,6 +32,9 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   if (a->batch <= 0 || a->heads <= 0 || a->len_q <= 0) return fail(IR_ERR_INVALID_ARG, "batch/heads/len_q must be > 0");
   if (a->n_refs < 0 || a->len_self < 0 || a->len_ref < 0) return fail(IR_ERR_INVALID_ARG, "negative length");
   const bool inc = (a->flags & IR_FLAG_INCLUDE_SELF) != 0;
+  if ((a->flags & ~(IR_FLAG_INCLUDE_SELF | IR_FLAG_Q_PRESCALED | IR_FLAG_OUT_F32)) != 0) return fail(IR_ERR_INVALID_ARG, "unknown flag bits 0x%x", a->flags);
+  if (a->reserved != 0) return fail(IR_ERR_INVALID_ARG, "reserved must be 0");
+  if (!ir_attn_variant_available(a->tuning)) return fail(IR_ERR_UNSUPPORTED, "tuning value %d is not available in this build", a->tuning);
   if (inc && a->len_self <= 0) return fail(IR_ERR_INVALID_ARG, "INCLUDE_SELF with len_self == 0");
   if (a->n_refs > 0 && a->len_ref <= 0) return fail(IR_ERR_INVALID_ARG, "n_refs > 0 with len_ref == 0");
   if (!inc && a->n_refs == 0) return fail(IR_ERR_INVALID_ARG, "empty key/value sequence");
@@ -63,6 +63,10 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->o_sb = a->o_sb; p->o_sl = a->o_sl; p->o_sh = a->o_sh;
   p->B = a->batch; p->H = a->heads; p->Lq = a->len_q; p->Ls = a->len_self; p->N = a->n_refs; p->Lr = a->len_ref;
   p->include_self = inc ? 1 : 0;
+  p->q_prescaled = (a->flags & IR_FLAG_Q_PRESCALED) ? 1 : 0;
+  p->out_f32 = (a->flags & IR_FLAG_OUT_F32) ? 1 : 0;
+  if ((p->q_prescaled || p->out_f32) && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_SP64)
+    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED / IR_FLAG_OUT_F32 are implemented by the default (SP64) kernel only");
   p->tiles_self = inc ? (a->len_self + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->tiles_ref = a->n_refs > 0 ? (a->len_ref + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->ntiles = p->tiles_self + a->n_refs * p->tiles_ref;
@@ -87,13 +91,11 @@ const char* ir_build_info(void) { return "instantrestore_hip gfx950 (CDNA4) hipc
 
 const char* ir_last_error_string(void) { return g_err; }
 
-int ir_set_attn_variant(int variant) { return g_variant.exchange(variant); }
-
 // 8 XCDs x 64 slots pieces of up to 256 rows, 64 fp32 of O + (max, sum) per row
 const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
   AttnKParams p;
   if (build_attn_params(args, &p, false) != IR_OK) return "";
-  const int v = g_variant.load() & 15;
+  const int v = args->tuning & 31;
   const bool fold = p.aa != nullptr;
   switch (v) {
     case 0: return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>")
@@ -114,7 +116,7 @@ int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream) {
   AttnKParams p;
   const int rc = build_attn_params(args, &p, true);
   if (rc != IR_OK) return rc;
-  const hipError_t e = ir_launch_shared_attn_fwd(p, args->dtype, g_variant.load(), (hipStream_t)stream);
+  const hipError_t e = ir_launch_shared_attn_fwd(p, args->dtype, args->tuning, (hipStream_t)stream);
   if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "shared_attn_fwd launch: %s", hipGetErrorString(e));
   return IR_OK;
 }
@@ -128,7 +130,7 @@ int ir_time_shared_attn_fwd(const ir_shared_attn_args* args, int32_t iters, void
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(IR_ERR_LAUNCH, "hipEventCreate failed");
   hipError_t e = hipEventRecord(e0, s);
-  for (int i = 0; i < iters && e == hipSuccess; ++i) e = ir_launch_shared_attn_fwd(p, args->dtype, g_variant.load(), s);
+  for (int i = 0; i < iters && e == hipSuccess; ++i) e = ir_launch_shared_attn_fwd(p, args->dtype, args->tuning, s);
   if (e == hipSuccess) e = hipEventRecord(e1, s);
   if (e == hipSuccess) e = hipEventSynchronize(e1);
   float ms = 0.f;

@@ -27,6 +27,8 @@ struct AttnKParams {
   int64_t o_sb, o_sl, o_sh;
   int B, H, Lq, Ls, N, Lr;
   int include_self;   // 0/1
+  int q_prescaled;    // IR_FLAG_Q_PRESCALED: q holds Q * scale * log2(e)   (shared_attn_fwd_sp.hip only)
+  int out_f32;        // IR_FLAG_OUT_F32: fp32 output, o_s* in fp32 elements  (shared_attn_fwd_sp.hip + combine)
   int tiles_self;     // ceil(Ls/64) if include_self else 0
   int tiles_ref;      // ceil(Lr/64)
   int ntiles;         // include_self*tiles_self + N*tiles_ref
@@ -88,7 +90,9 @@ hipError_t ir_launch_shared_attn_combine(const AttnKParams& p, int dtype, int qb
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64x8_pp(const AttnKParams& p, int dtype, hipStream_t s);
+hipError_t ir_launch_shared_attn_fwd_sp(const AttnKParams& p, int dtype, hipStream_t s);
 bool ir_attn_default_is_w64(const AttnKParams& p);
+bool ir_attn_variant_available(int variant);
 
 // Remainder split: `rem` items of the last, partially filled round (per XCD) on `slots` concurrently
 // resident workgroups.  Cutting each into k K/V-range pieces makes the round last ceil(rem*k/slots)/k of an

@@ -37,6 +37,7 @@
 #include "ir_common.h"
 #include "ir_kernels.h"
 
+#ifdef IR_ABLATIONS   // the first, straight-line kernel (variants 1/2) and its timing ablations: development builds only
 namespace {
 
 constexpr int KVB = IR_KV_TILE;            // 64 keys per tile
@@ -403,32 +404,42 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 }
 
 }  // namespace
+#endif  // IR_ABLATIONS
 
-// variant & 15 selects the kernel (tuning hook; 0 = default dispatch, see ir_attn_default_is_w64):
-//   13 64 query rows per wave, 8-wave (512-row) workgroups (shared_attn_fwd_w64.hip; default on long axes)
-//   12 the same in 4-wave (256-row) workgroups
-//   15 13 with rotated phases and the two wave groups of a workgroup one phase apart (ping-pong; see the kernel)
-//   10 software-pipelined 32-row kernel, 4 waves, asm-issued LDS-DMA staging, lazy max (shared_attn_fwd_pipe.hip;
-//      default everywhere else)        7 the same with an exact (every-change) rescale
+// variant & 15 selects the kernel (per-call tuning field of ir_shared_attn_args; 0 = default dispatch, see
+// ir_attn_default_kernel).  Product library:
+//   16 (IR_TUNE_SP) one wave per SIMD, 64 query rows per wave, software-pipelined (shared_attn_fwd_sp.hip)
+//   13 64 query rows per wave, 8-wave (512-row) workgroups (shared_attn_fwd_w64.hip)     12 the same, 4 waves
+//   10 software-pipelined 32-row kernel, 4 waves, asm-issued LDS-DMA staging, lazy max (shared_attn_fwd_pipe.hip)
+//    7 the same with an exact (every-change) rescale
 //   11 10 + pre-scaled Q, reference through the MFMA C operand (opt-in fast mode: one more rounding of Q)
 //   14 10 with the next tile's QK^T issued before the row max
-//   1/2 this file's straight-line kernel with 8 / 4 waves     3/4 pipelined, register staging, 4 / 8 waves
-//   6 pipelined + builtin LDS-DMA   8 ping-pong wave groups (shared_attn_fwd_pp.hip)
-//   9 straight schedule + asm DMA at 3 waves/SIMD
-// (tried and removed, see DESIGN.md 4.1: hoisted fragment reads, s_setprio, single-statement asm VALU)
-// variant >> 4: ablation bits - only in -DIR_ABLATIONS builds (timing experiments, WRONG results)
-// Default dispatch: the 64-rows-per-wave kernel in 8-wave (512-row) workgroups on the long query axes when
-// there is enough work to fill the chip with them - at least one full round of 512-row items, or long K/V
-// sequences whose remainder split fills it (the shared layers) - the pipelined 32-row kernel otherwise.
+// Development builds only (-DIR_ABLATIONS; documented experiments): 1/2 this file's straight-line
+// kernel with 8 / 4 waves, 3/4 pipelined with register staging, 6 pipelined + builtin LDS-DMA, 8 ping-pong wave
+// groups (shared_attn_fwd_pp.hip), 9 straight schedule at 3 waves/SIMD, 15 the 64-row kernel with rotated phases;
+// variant >> 5: ablation bits (timing experiments, WRONG results).
+bool ir_attn_variant_available(int variant) {
+  const int base = variant & 31;
+#ifdef IR_ABLATIONS
+  return base <= 16;
+#else
+  if ((variant >> 5) != 0) return false;
+  return base == 0 || base == 7 || (base >= 10 && base <= 14) || base == 16;
+#endif
+}
+
+// Default dispatch: on long K/V walks with enough (b, h, 256-row) items to fill the chip, the software-pipelined
+// one-wave-per-SIMD kernel; the 64-rows-per-wave kernel in 512-row workgroups when only that fills it ...
 bool ir_attn_default_is_w64(const AttnKParams& p) {
   const long items512 = (long)p.B * p.H * ((p.Lq + 511) / 512);
   return p.Lq >= 4096 && (items512 >= 256 || p.ntiles >= 128);
 }
 
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
+  if (!ir_attn_variant_available(variant)) return hipErrorInvalidValue;
 #ifdef IR_ABLATIONS
-  const int abl = variant >> 4;
-  if (abl != 0 && (variant & 15) == 3) return ir_launch_shared_attn_fwd_pipe_abl(p, abl, s);
+  const int abl = variant >> 5;
+  if (abl != 0 && (variant & 31) == 3) return ir_launch_shared_attn_fwd_pipe_abl(p, abl, s);
   if (abl != 0) {
     switch (abl & 7) {
       case 1: return launch<__bf16, 4, false, 1>(p, s);
@@ -441,28 +452,27 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
     }
   }
 #endif
-  const int base = variant & 15;
-  if (base == 0) {
-    // default: the 64-rows-per-wave kernel (AdaIN folded in a ratio frame, 512-row workgroups: half the K/V
-    // transfers per row of the 256-row form and 3-8 % faster wherever both were measured) on the long query
-    // axes of the 64x64-token class and above; the software-pipelined 32-row kernel (4 waves, asm-issued
-    // LDS-DMA staging, lazy max, LDS-resident fold totals) everywhere else - short axes leave the wide
-    // kernel too few items to fill the chip
-    if (ir_attn_default_is_w64(p)) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
-    return ir_launch_shared_attn_fwd_pipe(p, dtype, 14, s);   // 10 + next tile's QK^T before the row max: +1-3 % on the short axes
+  const int base = variant & 31;
+  if (p.q_prescaled || p.out_f32) return ir_launch_shared_attn_fwd_sp(p, dtype, s);   // implemented there only
+  switch (base) {
+    case 16: return ir_launch_shared_attn_fwd_sp(p, dtype, s);
+    case 0:
+      if (ir_attn_default_is_w64(p)) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
+      return ir_launch_shared_attn_fwd_pipe(p, dtype, 14, s);
+    case 7: case 10: case 11: case 14: return ir_launch_shared_attn_fwd_pipe(p, dtype, base, s);
+    case 12: return ir_launch_shared_attn_fwd_w64(p, dtype, s);
+    case 13: return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
+#ifdef IR_ABLATIONS
+    case 3: return ir_launch_shared_attn_fwd_pipe(p, dtype, 4, s);   // register staging, 4 waves
+    case 4: return ir_launch_shared_attn_fwd_pipe(p, dtype, 8, s);   // register staging, 8 waves
+    case 6: case 9: return ir_launch_shared_attn_fwd_pipe(p, dtype, base, s);
+    case 8: return ir_launch_shared_attn_fwd_pp(p, dtype, s);
+    case 15: return ir_launch_shared_attn_fwd_w64x8_pp(p, dtype, s);
+    case 1: case 2: {
+      const int nw = (base == 1) ? 8 : 4;
+      return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);
+    }
+#endif
+    default: return hipErrorInvalidValue;
   }
-  if (base == 3) return ir_launch_shared_attn_fwd_pipe(p, dtype, 4, s);  // software-pipelined, 4 waves, register staging
-  if (base == 4) return ir_launch_shared_attn_fwd_pipe(p, dtype, 8, s);  // software-pipelined, 8 waves
-  if (base == 6) return ir_launch_shared_attn_fwd_pipe(p, dtype, 6, s);  // pipelined, 4 waves, LDS-DMA staging
-  if (base == 7) return ir_launch_shared_attn_fwd_pipe(p, dtype, 7, s);  // same, DMA issued from asm
-  if (base == 9) return ir_launch_shared_attn_fwd_pipe(p, dtype, 9, s);  // straight schedule + asm DMA, 3 waves/SIMD
-  if (base == 10) return ir_launch_shared_attn_fwd_pipe(p, dtype, 10, s);  // default + lazy max (deferred rescale)
-  if (base == 11) return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);  // + pre-scaled Q, reference through the MFMA C operand
-  if (base == 12) return ir_launch_shared_attn_fwd_w64(p, dtype, s);  // 64 rows per wave
-  if (base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);  // 64 rows per wave, 8-wave (512-row) workgroups
-  if (base == 15) return ir_launch_shared_attn_fwd_w64x8_pp(p, dtype, s);  // 13 with the two wave groups one phase apart
-  if (base == 14) return ir_launch_shared_attn_fwd_pipe(p, dtype, 14, s);  // pipelined, QK^T of the next tile issued before the row max
-  if (base == 8) return ir_launch_shared_attn_fwd_pp(p, dtype, s);  // ping-pong wave groups (shared_attn_fwd_pp.hip)
-  const int nw = (base == 1) ? 8 : 4;
-  return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);
 }

@@ -591,8 +591,9 @@ __global__ void __launch_bounds__(256) shared_attn_combine_kernel(const AttnKPar
     acc += x * w;
   }
   const float inv = 1.0f / L;
-  T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh + grp * 4;
-  *(v4*)op = __builtin_convertvector(acc * inv, v4);
+  const int64_t off = (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh + grp * 4;
+  if (p.out_f32) *(f32x4*)((float*)p.out + off) = acc * inv;   // IR_FLAG_OUT_F32: the result before the 16-bit rounding
+  else *(v4*)((T*)p.out + off) = __builtin_convertvector(acc * inv, v4);
   if (p.lse != nullptr && grp == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = M * p.scale + __logf(L);
 }
 
@@ -630,14 +631,17 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
 template <typename T>
 hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   const bool fold = (p.aa != nullptr);
+#ifdef IR_ABLATIONS
   if (nw == 8) return fold ? launch<T, 8, true>(p, s) : launch<T, 8, false>(p, s);
   if (nw == 6) return fold ? launch<T, 4, true, 64>(p, s) : launch<T, 4, false, 64>(p, s);  // LDS-DMA staging
+  if (nw == 9) return fold ? launch<T, 4, true, 256>(p, s) : launch<T, 4, false, 256>(p, s);  // straight schedule, 3 waves/SIMD
+  if (nw == 4) return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);             // register staging
+#endif
   if (nw == 7) return fold ? launch<T, 4, true, 128>(p, s) : launch<T, 4, false, 128>(p, s);  // LDS-DMA from asm
   if (nw == 10) return fold ? launch<T, 4, true, 128 | 1024>(p, s) : launch<T, 4, false, 128 | 1024>(p, s);  // asm DMA + lazy max
   if (nw == 11) return fold ? launch<T, 4, true, 128 | 1024 | 2048>(p, s) : launch<T, 4, false, 128 | 1024 | 2048>(p, s);  // + pre-scaled Q, reference through the C operand
   if (nw == 14) return fold ? launch<T, 4, true, 128 | 1024 | 4096>(p, s) : launch<T, 4, false, 128 | 1024 | 4096>(p, s);  // + QK^T of the next tile first
-  if (nw == 9) return fold ? launch<T, 4, true, 256>(p, s) : launch<T, 4, false, 256>(p, s);  // straight schedule, 3 waves/SIMD
-  return fold ? launch<T, 4, true>(p, s) : launch<T, 4, false>(p, s);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace

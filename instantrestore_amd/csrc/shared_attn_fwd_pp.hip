@@ -19,6 +19,7 @@
 // 2j-3 (after the last read of pair j-3) and waited for before the barrier closing half-step
 // 2j-2, i.e. with two half-steps of flight time.  256 query rows per workgroup halves the
 // global->LDS traffic and the barriers per flop relative to the 4-wave kernels.
+#ifdef IR_ABLATIONS   // documented experiment (variant 8): development builds only
 #include <type_traits>
 
 #include "ir_common.h"
@@ -420,3 +421,5 @@ hipError_t ir_launch_shared_attn_fwd_pp(const AttnKParams& p, int dtype, hipStre
   if (dtype == 1) return fold ? launch<__bf16, true>(p, s) : launch<__bf16, false>(p, s);
   return fold ? launch<_Float16, true>(p, s) : launch<_Float16, false>(p, s);
 }
+
+#endif  // IR_ABLATIONS

@@ -561,9 +561,11 @@ static hipError_t launch_x8(const AttnKParams& p, int dtype, hipStream_t s) {
   return dtype == 1 ? launch<__bf16, false, 8, PP>(p, s) : launch<_Float16, false, 8, PP>(p, s);
 }
 
+#ifdef IR_ABLATIONS   // variant 15 (rotated phases, wave groups one phase apart): development builds only
 hipError_t ir_launch_shared_attn_fwd_w64x8_pp(const AttnKParams& p, int dtype, hipStream_t s) {  // ping-pong wave groups
   return launch_x8<true>(p, dtype, s);
 }
+#endif
 
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s) {  // 8-wave (512-row) workgroups
   return launch_x8<false>(p, dtype, s);

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -96,11 +97,15 @@ def _ref(t: torch.Tensor, heads: int, name: str) -> torch.Tensor:
     return t
 
 
-def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split=True):
+def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split=True,
+               q_prescaled=False):
     a = _lib.SharedAttnArgs()
     a.struct_size = C.sizeof(_lib.SharedAttnArgs)
     a.dtype = _dtype_code(q)
-    a.flags = _lib.IR_FLAG_INCLUDE_SELF if include_self else 0
+    a.flags = (_lib.IR_FLAG_INCLUDE_SELF if include_self else 0) | (_lib.IR_FLAG_Q_PRESCALED if q_prescaled else 0)
+    if out is not None and out.dtype == torch.float32:
+        a.flags |= _lib.IR_FLAG_OUT_F32
+    a.tuning = _TUNING
     a.batch, a.len_q, _ = q.shape
     a.heads = heads
     a.scale = float(scale)
@@ -184,17 +189,22 @@ def _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain):
 @_on_tensor_device
 def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
                      include_self: bool = True, adain: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
-                     return_lse: bool = False, split: bool = True):
+                     return_lse: bool = False, split: bool = True, q_prescaled: bool = False,
+                     out_dtype: Optional[torch.dtype] = None):
     """Fused extended self-attention (``ir_shared_attn_fwd``).
 
     Returns ``out`` (B, Lq, H*64) in q's dtype [and ``lse`` (B, H, Lq) fp32].  ``adain`` is the
     (a, b) pair from :func:`adain_stats`; the reference-V renormalisation happens inside the
-    kernel's V staging.
+    kernel's V staging.  ``q_prescaled``: ``q`` already holds ``Q * scale * log2(e)`` (``IR_FLAG_Q_PRESCALED``: the
+    fused q/k/v projection folds the factor into its weights; ``scale`` stays the reference's ``attn.scale``).
+    ``out_dtype=torch.float32`` returns the result before its rounding to 16 bit (``IR_FLAG_OUT_F32``, parity tests).
     """
     q, k_self, v_self, ref_k, ref_v = _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain)
-    out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=q.dtype, device=q.device)
+    if out_dtype not in (None, q.dtype, torch.float32):
+        raise TypeError("out_dtype must be the compute dtype or torch.float32")
+    out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=out_dtype or q.dtype, device=q.device)
     lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if return_lse else None
-    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split)
+    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split, q_prescaled)
     sink = EVENT_SINK
     if sink is not None and sink[0](q, ref_k, adain):   # bench.py: HIP events around chosen launches, in situ
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -209,11 +219,12 @@ def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, s
 
 @_on_tensor_device
 def time_shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
-                          include_self: bool = True, adain=None, iters: int = 10, split: bool = True) -> float:
+                          include_self: bool = True, adain=None, iters: int = 10, split: bool = True,
+                          q_prescaled: bool = False) -> float:
     """Average ms per launch measured with HIP events on the launch stream (``bench.py``)."""
     q, k_self, v_self, ref_k, ref_v = _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain)
     out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=q.dtype, device=q.device)
-    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, None, split)
+    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, None, split, q_prescaled)
     ms = C.c_float(0.0)
     _lib.check(_lib.lib().ir_time_shared_attn_fwd(C.byref(args), int(iters), _stream(), C.byref(ms)),
                "ir_time_shared_attn_fwd")
@@ -428,7 +439,15 @@ def preprocess_lanczos(descs, size: int, dtype: torch.dtype, device: torch.devic
     return out
 
 
+_TUNING = int(os.environ.get("IR_ATTN_VARIANT", "0") or 0)
+
+
 def set_attn_variant(variant: int) -> int:
-    """tuning hook for benchmarks/tests: 0 = default dispatch, 13 / 12 = 64-row kernel in 8- / 4-wave workgroups,
-    10 = pipelined 32-row kernel, 11 = opt-in pre-scaled-Q fast mode, ... (csrc/shared_attn_fwd.hip lists them)"""
-    return _lib.lib().ir_set_attn_variant(int(variant))
+    """tuning hook for benchmarks / A-B tests: the value goes into the per-call ``tuning`` field of the C ABI's
+    argument block (``IR_TUNE_*`` in include/instantrestore_hip.h; 0 = default dispatch, 16 = one-wave-per-SIMD
+    pipelined kernel, 13 / 12 = 64-row kernel in 8- / 4-wave workgroups, 10 / 14 = pipelined 32-row kernel, 11 = its
+    pre-scaled-Q form).  ``IR_ATTN_VARIANT=<n>`` in the environment sets the initial value.  Returns the previous one.
+    The C library itself holds no such state."""
+    global _TUNING
+    prev, _TUNING = _TUNING, int(variant)
+    return prev

@@ -48,7 +48,7 @@ def test_struct_mirror_matches_header_field_order():
         else:
             fields.append(names.lstrip("*"))
     assert fields == [f[0] for f in _lib.SharedAttnArgs._fields_]
-    assert C.sizeof(_lib.SharedAttnArgs) == 10 * 4 + 9 * 8 + 20 * 8 + 16
+    assert C.sizeof(_lib.SharedAttnArgs) == 10 * 4 + 9 * 8 + 20 * 8 + 16 + 8
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
@@ -70,11 +70,12 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
 
 
 def test_variant_env_var_is_applied_at_load():
-    """IR_ATTN_VARIANT=<n> selects a kernel variant for the whole process without code changes"""
+    """IR_ATTN_VARIANT=<n> selects a kernel variant for the whole process without code changes (the value rides
+    in the per-call `tuning` field; the C library keeps no such state)"""
     import subprocess
     import sys
-    code = ("import sys; sys.path.insert(0, %r); from instantrestore_amd import _lib; "
-            "print(_lib.lib().ir_set_attn_variant(0))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    code = ("import sys; sys.path.insert(0, %r); from instantrestore_amd import ops; "
+            "print(ops.set_attn_variant(0))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     env = dict(os.environ, IR_ATTN_VARIANT="11")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr

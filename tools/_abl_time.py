@@ -1,0 +1,15 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+import torch
+from instantrestore_amd import ops
+from instantrestore_amd.roofline import attn_flops
+B, L, C, H, N = 8, 4096, 320, 5, 4
+torch.manual_seed(0)
+q, k, v = (torch.randn(B, L, C, device="cuda").to(torch.bfloat16) for _ in range(3))
+rk = torch.randn(B, N, L, C, device="cuda").to(torch.bfloat16); rv = torch.randn(B, N, L, C, device="cuda").to(torch.bfloat16)
+ops.set_attn_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 16)
+kw = dict(heads=H, scale=0.125, include_self=True, q_prescaled=(len(sys.argv) > 2))
+if len(sys.argv) > 2: q = (q.float() * 0.125 * 1.4426950408889634).to(torch.bfloat16)
+ops.time_shared_attention(q, k, v, rk, rv, iters=3, **kw)
+ms = min(ops.time_shared_attention(q, k, v, rk, rv, iters=10, **kw) for _ in range(3))
+print(f"{os.environ.get('IR_LIB_PATH','default')[-16:]}: {ms:.4f} ms {attn_flops(B, L, 5 * L, C) / ms / 1e9:.0f} TF/s")

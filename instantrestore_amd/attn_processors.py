@@ -210,16 +210,20 @@ class AttnProcessor(nn.Module):
                                           # the list of all capturing processors of the UNet
         self.record_events = False        # True: record `ready` on the current stream once K/V are stashed
         self.ready = None
+        self.stream = None                # HIP stream the K/V were produced on (kv_harvest orders its zero fill after it)
 
     def reset(self):
         self.keys, self.values = None, None
         self.is_self_attn = None
         self.ready = None
+        self.stream = None
 
     def _mark_ready(self):
-        if self.record_events and self.keys.is_cuda:
-            self.ready = torch.cuda.Event()
-            self.ready.record(torch.cuda.current_stream(self.keys.device))
+        if self.keys.is_cuda:
+            self.stream = torch.cuda.current_stream(self.keys.device)
+            if self.record_events:
+                self.ready = torch.cuda.Event()
+                self.ready.record(self.stream)
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
@@ -373,6 +377,8 @@ def register_attention_processor(unet, cfg, save_self_attentions: bool = False):
                                        use_adain=cfg.use_adain, train_input=cfg.train_input)
         procs[name] = proc.to(unet.device, dtype=unet.dtype)
     unet.set_attn_processor(procs)
+    _lora.invalidate_all(unet)            # (re-)registration starts from freshly folded projection weights
+    _lora.install_invalidation_hook(unet)
 
 
 def register_attention_processor_kv_unet(unet):
@@ -386,6 +392,8 @@ def register_attention_processor_kv_unet(unet):
         else:
             procs[name] = proc
     unet.set_attn_processor(procs)
+    _lora.invalidate_all(unet)
+    _lora.install_invalidation_hook(unet)
 
 
 __all__ = ["adain", "AttnProcessor", "FaceIDAttnProcessor", "SharedAttnProcessor",

@@ -370,11 +370,15 @@ hipError_t launch(const LinearKParams& p0, hipStream_t s) {
     p.nsplit = nsplit;
     constexpr int KSH = 5;
     const size_t dyn = (size_t)2 * (2 * KSH) * SUB_BYTES + 2 * 4 * 8192;
-    static bool attr_set = false;
-    if (!attr_set) {
+    // the opt-in to > 64 KiB of dynamic LDS belongs to the function ON THE CURRENT DEVICE: one flag per device
+    // (a process may hold tensors on several), idempotent, so a race between threads only repeats the call
+    static bool attr_set[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
+    if (!attr_set[dev]) {
       hipError_t ea = hipFuncSetAttribute((const void*)linear_ksplit_kernel<T, KSH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
       if (ea != hipSuccess) return ea;
-      attr_set = true;
+      attr_set[dev] = true;
     }
     hipLaunchKernelGGL((linear_ksplit_kernel<T, KSH>), dim3((unsigned)(mblocks * nsplit)), dim3(512), dyn, s, p);
     return hipGetLastError();

@@ -539,12 +539,14 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   size_t dyn_lds = 0;
   if (PP) {
     dyn_lds = (size_t)2 * 4 * TILE_BYTES + (size_t)NW * 8192;   // ring of 4 K/V pairs + the waves' Q fragments
-    static bool attr_set = false;   // per instantiation; idempotent, so a race only repeats the call
-    if (!attr_set) {
+    static bool attr_set[64] = {};   // per instantiation and per device; idempotent, so a race only repeats the call
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
+    if (!attr_set[dev]) {
       hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, PP>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
       if (ea != hipSuccess) return ea;
-      attr_set = true;
+      attr_set[dev] = true;
     }
   }
   hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, PP>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);

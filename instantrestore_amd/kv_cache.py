@@ -46,7 +46,11 @@ class ReferenceKVCache:
         keys, values = compute()
         if len(keys) != len(values) or any(k.shape[0] != 1 or k.shape != v.shape for k, v in zip(keys, values)):
             raise ValueError("compute() must return matching lists of (1, N, L, C) tensors")
-        entry = ([k.detach() for k in keys], [v.detach() for v in values])
+        # compact copies: the harvested tensors are strided views of the capture layers' fused (B*N, L, 3C) projection
+        # output - caching the views would pin that whole buffer (dead Q third, every other identity of the batch) per
+        # entry and eviction would free nothing.  One entry = 2 * 9 layers * N * L * C * 2 bytes.
+        entry = ([k.detach().clone(memory_format=torch.contiguous_format) for k in keys],
+                 [v.detach().clone(memory_format=torch.contiguous_format) for v in values])
         self._store[identity] = entry
         while len(self._store) > self.max_identities:
             self._store.popitem(last=False)
@@ -61,6 +65,11 @@ class ReferenceKVCache:
         keys = [torch.cat([e[0][l] for e in entries], dim=0) for l in range(n_layers)]
         values = [torch.cat([e[1][l] for e in entries], dim=0) for l in range(n_layers)]
         return keys, values
+
+    def nbytes(self, identity: Hashable) -> int:
+        """device bytes held for one cached identity"""
+        ks, vs = self._store[identity]
+        return sum(t.untyped_storage().nbytes() for t in ks + vs)
 
     def invalidate(self, identity: Hashable = None) -> None:
         if identity is None:

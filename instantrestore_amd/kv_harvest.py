@@ -30,21 +30,32 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
     procs = [p for p in original_unet.attn_processors.values() if type(p) in [_ap.AttnProcessor]]
     if not procs:
         raise RuntimeError("no AttnProcessor on this UNet: call register_attention_processor_kv_unet first")
-    keys, values, events = [], [], []
+    keys, values, events, streams = [], [], [], []
     for p in procs:
         if p.keys is None or p.values is None:
             raise RuntimeError("reference UNet has not been run since the last reset()")
         events.append(p.ready)
+        streams.append(getattr(p, "stream", None))
         k = p.keys.reshape(-1, n_refs, p.keys.shape[1], p.keys.shape[2])
         v = p.values.reshape(-1, n_refs, p.values.shape[1], p.values.shape[2])
         keys.append(k)
         values.append(v)
     valid = torch.as_tensor(valid_indices)
     if bool((valid < n_refs).any()):
-        heads = keys[0].shape[-1] // _ops.HEAD_DIM
+        if keys[0].is_cuda:
+            # The zero fill runs on the CURRENT stream and rewrites the stashes in place.  The reference does it after
+            # the whole reference forward (pix2pix_turbo.py:255-273); when that forward was enqueued on another stream
+            # (two-stream pipelining) the per-layer `ready` events are NOT enough - they are recorded before the
+            # layer's own attention reads K/V - so this stream first waits for everything the capture stream(s) have
+            # been given, i.e. the end of the reference forward.
+            cur = torch.cuda.current_stream(keys[0].device)
+            for st in {s for s in streams if s is not None and s != cur}:
+                cur.wait_stream(st)
+            for k, v in zip(keys, values):   # allocated on the capture stream, written here
+                k.record_stream(cur)
+                v.record_stream(cur)
         for k, v in zip(keys, values):
             _ops.zero_invalid_refs(k, v, valid, heads=k.shape[-1] // _ops.HEAD_DIM)
-        del heads
     if reset:
         for p in procs:
             p.reset()

@@ -8,7 +8,10 @@ linear map is one GEMM against ``W + scaling * B @ A`` - what peft's own ``merge
 computes.  Nothing is written back to the modules (checkpoints keep loading ``strict=True``,
 test.py:47-50): the folded weight lives in a per-module cache keyed on the identity and
 ``_version`` of every tensor that went into it, so optimiser steps or ``load_state_dict``
-invalidate it.
+invalidate it.  Writes through ``.data`` (``w.data.copy_``, ``w.data -= d``: diffusers'
+``EMAModel.copy_to``, manual weight surgery) do NOT bump ``_version``: call :func:`invalidate` /
+:func:`invalidate_all` after them.  The registration functions and a ``load_state_dict`` post hook
+installed by them do so on their own.
 
 peft is not installed in this image; the wrapper is recognised structurally
 (``base_layer`` / ``lora_A`` / ``lora_B`` / ``scaling`` / ``active_adapters``), which is the
@@ -115,3 +118,29 @@ def cached_cast(owner, slot: str, t: torch.Tensor, dtype) -> torch.Tensor:
         cache = (key, t.detach().to(dtype))
         owner.__dict__[slot] = cache
     return cache[1]
+
+
+_SLOTS = ("_ir_qkv_cache", "_ir_out_cache", "_ir_out_bias_cache")
+
+
+def invalidate(attn) -> None:
+    """drop the folded / fused weights cached on one attention module (they are rebuilt on its next call)"""
+    for slot in _SLOTS:
+        attn.__dict__.pop(slot, None)
+
+
+def invalidate_all(module: nn.Module) -> int:
+    """:func:`invalidate` on every sub-module of ``module`` that carries a cache; returns how many did"""
+    n = 0
+    for m in module.modules():
+        if any(slot in m.__dict__ for slot in _SLOTS):
+            invalidate(m)
+            n += 1
+    return n
+
+
+def install_invalidation_hook(module: nn.Module) -> None:
+    """``load_state_dict`` on ``module`` (checkpoint load, test.py:47-50) drops every cached folded weight below it"""
+    if getattr(module, "_ir_invalidation_hook", None) is None and hasattr(module, "register_load_state_dict_post_hook"):
+        module._ir_invalidation_hook = module.register_load_state_dict_post_hook(
+            lambda mod, incompatible_keys: invalidate_all(mod))

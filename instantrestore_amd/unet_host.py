@@ -19,7 +19,7 @@ with 1280/640/320 channels = 20/10/5 heads of 64; restore_dataset.py:71-75) and 
 weights - no checkpoint is reachable offline.  Between attention stages the activations are moved
 with cheap token-space stand-ins (2x2 mean pooling / nearest up-sampling + a ``Linear``) where the
 real UNet has ResNet/conv blocks; they exist only so every attention sees a tensor of the right
-shape.  Tests, ``smoke()`` and the end-to-end leg of ``bench.py`` use it.
+shape.  Tests, ``smoke()``, ``examples/synthetic_inference.py`` and ``bench.py --e2e`` use it.
 """
 from __future__ import annotations
 
@@ -163,10 +163,8 @@ class AttnTopologyUNet(nn.Module):
     def set_attn_processor(self, processor, _remove_lora: bool = False) -> None:
         count = len(self.attn_processors)
         if isinstance(processor, dict) and len(processor) != count:
-            raise ValueError(
-                f"A dict of processors was passed, but the number of processors {len(processor)} does not "
-                f"match the number of attention layers: {count}. Please make sure to pass {count} processor classes."
-            )
+            raise ValueError(f"set_attn_processor: got a dict with {len(processor)} entries for {count} attention layers "
+                             "(one processor per layer, keyed '<module path>.processor')")
 
         def visit(name: str, module: nn.Module):
             if hasattr(module, "set_processor"):

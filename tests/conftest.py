@@ -16,16 +16,6 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
-def pytest_sessionstart(session):
-    """A fresh checkout has no libinstantrestore_hip.so (built artefacts are not in history): build it once, in
-    tree, exactly as __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU, ~30 s)."""
-    lib = os.path.join(REPO, "instantrestore_amd", "libinstantrestore_hip.so")
-    script = os.path.join(REPO, "instantrestore_amd", "csrc", "build.sh")
-    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
-        import subprocess
-        subprocess.run(["bash", script], check=True, timeout=1800, stdout=subprocess.DEVNULL)
-
-
 def bits_to_f32(u16: np.ndarray, lowp: str) -> np.ndarray:
     """raw 16-bit patterns (fp16 / bf16) -> float32 values"""
     u16 = np.asarray(u16, dtype=np.uint16)

@@ -235,8 +235,29 @@ def test_golden_shared_processor(ops, golden, m):
         p_ref = golden.arr(m, "probs")
         p = proc.attention_probs
         assert tuple(p.shape) == p_ref.shape and p.dtype == dtype
-        # projections rounded to 16 bit move peaky logits by O(0.1): wider band there
-        assert np.abs(p.float().cpu().numpy() - p_ref).max() <= (16 if m["peaky"] else 4) * TOL[dtype]
+        pn = p.float().cpu().numpy()
+        if not m["peaky"]:
+            assert np.abs(pn - p_ref).max() <= 4 * TOL[dtype]
+        # The autocast projections round q / k to 16 bit before the scores are formed (so does the reference's own
+        # 16-bit run); on the peaky cases that alone moves logits of O(100) by O(0.1).  To hold the dump path to the
+        # same 4 x TOL there, the reference probabilities are re-derived from q / k rounded the way the projection
+        # GEMM rounds them (fp32 accumulation, one rounding) - what remains is the kernel's own error.
+        Hh, Lq = m["H"], m["L"]
+        hid = torch.from_numpy(golden.arr(m, "hidden")).double()
+        r16 = lambda t: t.float().to(dtype).double()
+        q16 = r16(hid @ torch.from_numpy(golden.arr(m, "wq")).double().T)
+        k16 = r16(hid @ torch.from_numpy(golden.arr(m, "wk")).double().T)
+        segs = ([k16] if m["train_input"] else []) + [torch.from_numpy(golden.arr(m, "ref_k")).double()[:, n] for n in range(m["N"])]
+        kext = torch.cat(segs, dim=1)                                               # [self] ++ ref 0 ++ ...
+        hsplit = lambda t: t.reshape(t.shape[0], t.shape[1], Hh, 64).permute(0, 2, 1, 3)
+        p2 = torch.softmax(hsplit(q16) @ hsplit(kext).transpose(-1, -2) * 0.125, dim=-1).numpy()
+        assert np.abs(pn - p2).max() <= 4 * TOL[dtype], np.abs(pn - p2).max()
+        # K/V block order: attention mass per block ([self], ref 0, ref 1, ...) against the reference's own dump
+        nblk = m["N"] + int(m["train_input"])
+        w = p_ref.shape[-1] // nblk
+        mass = lambda a: a.reshape(*a.shape[:-1], nblk, w).sum(-1)
+        assert np.abs(mass(pn) - mass(p2)).max() <= 4 * TOL[dtype]
+        assert np.abs(mass(pn) - mass(p_ref)).max() <= (8 if m["peaky"] else 4) * TOL[dtype]
     assert len(proc.state_dict()) == 0
 
 
@@ -281,10 +302,12 @@ FULL = [
     (4096, 5, 4, torch.float16, False),
     (1024, 10, 8, torch.bfloat16, True),
     (16384, 5, 4, torch.float16, True),   # config 5: 1024 px, Lkv = 81920 (the largest layer in BASELINE.json)
+    (4096, 5, 8, torch.bfloat16, True),   # config 4's dominant layer: eight references, Lkv = 36864
+    (4096, 5, 8, torch.float16, False),   # the same with train_input = false, Lkv = 32768
 ]
 
 
-@pytest.mark.parametrize("L,H,N,dtype,inc", FULL, ids=["L4096N4bf16t1", "L4096N4f16t0", "L1024N8bf16t1", "L16384N4f16t1"])
+@pytest.mark.parametrize("L,H,N,dtype,inc", FULL, ids=["L4096N4bf16t1", "L4096N4f16t0", "L1024N8bf16t1", "L16384N4f16t1", "L4096N8bf16t1", "L4096N8f16t0"])
 def test_full_size_layer_sampled_rows_and_properties(ops, L, H, N, dtype, inc):
     gen = torch.Generator().manual_seed(4242)
     B, C = (1 if L > 4096 else 2), H * 64

@@ -1,0 +1,212 @@
+"""GPU tests added in round 2: rows of SURVEY.md section 8 that were covered on the CPU shim only (reference K/V cache
+and early exit on the device, LoRA fold on the device), the two-stream harvest with a zero fill, and the statement of
+the bf16 tolerance with the kernel's result BEFORE its rounding to 16 bit (IR_FLAG_OUT_F32)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import shared_attn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _hosts(seed_kv=1, seed_main=2, narrow=True):
+    from types import SimpleNamespace
+    import __graft_entry__ as ge
+    from face_replace.models.attn_processors import register_attention_processor, register_attention_processor_kv_unet
+    from instantrestore_amd.unet_host import AttnTopologyUNet
+    kw = dict(block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4), cross_attention_dim=64) if narrow else {}
+    cfg = SimpleNamespace(use_adain=True, train_input=True, condition_on_face_embeds=False)
+    kv_unet = AttnTopologyUNet(seed=seed_kv, **kw).cuda()
+    unet = AttnTopologyUNet(seed=seed_main, **kw).cuda()
+    ge.register_attention_processor_kv_unet_default(kv_unet, cfg)
+    register_attention_processor_kv_unet(kv_unet)
+    register_attention_processor(unet, cfg)
+    return kv_unet, unet
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_early_exit_and_cache_equal_recomputed_kv_on_the_device(dtype):
+    """SURVEY 8f rank 2 on the device: (1) the K/V lists harvested with early exit are bit-identical to the full
+    reference forward's; (2) a batch assembled from the per-identity cache, fed to the main UNet, gives the same bytes
+    as recomputed K/V; (3) a cache entry holds N*L*C*2 bytes per tensor - compact copies, not views of the fused QKV
+    buffer of the whole batch."""
+    from instantrestore_amd.kv_cache import ReferenceKVCache
+    from instantrestore_amd.kv_harvest import get_conditioning_keys_values
+    kv_unet, unet = _hosts()
+    B, N, S = 3, 2, 16
+    g = torch.Generator().manual_seed(11)
+    refs = torch.randn(B * N, 4, S, S, generator=g).cuda()
+    text = torch.randn(1, 77, 64, generator=g).cuda()
+    x = torch.randn(B, 4, S, S, generator=g).cuda()
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        k_full, v_full = get_conditioning_keys_values(kv_unet, refs, None, text.repeat(B * N, 1, 1), N, [N] * B)
+        k_full, v_full = [t.clone() for t in k_full], [t.clone() for t in v_full]
+        k_ee, v_ee = get_conditioning_keys_values(kv_unet, refs, None, text.repeat(B * N, 1, 1), N, [N] * B, early_exit=True)
+        assert len(k_ee) == len(k_full) == 9
+        for a, b in zip(k_full + v_full, k_ee + v_ee):
+            assert a.shape == b.shape and torch.equal(a, b)
+        y_ref = unet(x, None, encoder_hidden_states=text.repeat(B, 1, 1),
+                     cross_attention_kwargs={"ref_keys": k_full, "ref_values": v_full}).sample
+        cache = ReferenceKVCache(max_identities=8)
+        for b in range(B):
+            def compute(b=b):
+                ks, vs = get_conditioning_keys_values(kv_unet, refs[b * N:(b + 1) * N], None, text.repeat(N, 1, 1), N, [N],
+                                                      early_exit=True)
+                return ks, vs
+            cache.get_or_compute(f"id{b}", compute)
+        # recomputed per identity, without the cache: the bytes the cache must hand back
+        fresh = [get_conditioning_keys_values(kv_unet, refs[b * N:(b + 1) * N], None, text.repeat(N, 1, 1), N, [N], early_exit=True)
+                 for b in range(B)]
+        fresh = [([k.clone() for k in ks], [v.clone() for v in vs]) for ks, vs in fresh]
+        tol = {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+        for b in range(B):
+            ks, vs = cache.get_or_compute(f"id{b}", lambda: (_ for _ in ()).throw(AssertionError("must be a hit")))
+            for l in range(9):
+                assert torch.equal(ks[l], fresh[b][0][l]) and torch.equal(vs[l], fresh[b][1][l])
+                # identities are independent: the per-identity harvest is the batch harvest's slice up to the GEMM
+                # library's batch-size dependent summation order (different M -> different tiling)
+                assert (ks[l][0].float() - k_full[l][b].float()).abs().max().item() <= 4 * tol * max(1.0, k_full[l].float().abs().max().item())
+                assert ks[l].is_contiguous() and ks[l].untyped_storage().nbytes() == ks[l].numel() * ks[l].element_size()
+        want_bytes = 2 * sum(k.numel() // B * k.element_size() for k in k_full)
+        assert cache.nbytes("id0") == want_bytes
+        k_c, v_c = cache.assemble([f"id{b}" for b in range(B)])
+        k_r = [torch.cat([fresh[b][0][l] for b in range(B)], dim=0) for l in range(9)]
+        v_r = [torch.cat([fresh[b][1][l] for b in range(B)], dim=0) for l in range(9)]
+        kw = dict(encoder_hidden_states=text.repeat(B, 1, 1))
+        y_c = unet(x, None, cross_attention_kwargs={"ref_keys": k_c, "ref_values": v_c}, **kw).sample
+        y_r = unet(x, None, cross_attention_kwargs={"ref_keys": k_r, "ref_values": v_r}, **kw).sample
+    assert torch.equal(y_r, y_c)                      # cached K/V == recomputed K/V through the main UNet, bit for bit
+    assert (y_ref.float() - y_c.float()).abs().max().item() <= 8 * tol * max(1.0, y_ref.float().abs().max().item())
+    assert cache.hits == B and cache.misses == B
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_lora_fold_on_the_device_against_float64(dtype):
+    """peft-style LoRA wrappers on to_q/k/v/out (pix2pix_turbo.py:171-179) folded into the fused QKV / out GEMMs on the
+    device: against a float64 evaluation of base + scaling * B A, through the whole processor (projections, AdaIN
+    statistics, fused attention, out projection)."""
+    from test_lora_fold import PeftLikeLinear
+    from face_replace.models.attn_processors import SharedAttnProcessor
+    from instantrestore_amd.attention import Attention
+    from instantrestore_amd import lora_fold
+    torch.manual_seed(5)
+    H, L, N, B = 2, 96, 3, 2
+    C = H * 64
+    attn = Attention(query_dim=C, heads=H, dim_head=64,
+                     processor=SharedAttnProcessor(self_attn_idx=0, use_adain=True, train_input=True))
+    attn.to_q, attn.to_k, attn.to_v = (PeftLikeLinear(m, r=8, alpha=16) for m in (attn.to_q, attn.to_k, attn.to_v))
+    attn.to_out[0] = PeftLikeLinear(attn.to_out[0], r=8, alpha=16)
+    attn = attn.eval().cuda()
+    x = torch.randn(B, L, C)
+    rk, rv = torch.randn(B, N, L, C).to(dtype), (torch.randn(B, N, L, C) * 0.8 + 0.2).to(dtype)
+
+    def w_eff(m):
+        a, b = m.lora_A["default"].weight.double().cpu(), m.lora_B["default"].weight.double().cpu()
+        return m.base_layer.weight.double().cpu() + m.scaling["default"] * (b @ a)
+
+    f = lambda t: t.detach().double().numpy()
+    want, _, _ = O.shared_attn_processor_np(f(x), f(w_eff(attn.to_q)), f(w_eff(attn.to_k)), f(w_eff(attn.to_v)),
+                                            f(w_eff(attn.to_out[0])), f(attn.to_out[0].base_layer.bias.double().cpu()),
+                                            f(rk.float()), f(rv.float()), H, use_adain=True, train_input=True,
+                                            dtype=np.float64, return_probs=True)
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        got = attn(x.cuda(), ref_keys=[rk.cuda()], ref_values=[rv.cuda()])
+    tol = {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    assert np.abs(got.float().cpu().numpy() - want).max() <= 2 * tol * max(1.0, np.abs(want).max())
+    assert all(m.calls == 0 for m in (attn.to_q, attn.to_k, attn.to_v, attn.to_out[0])), "wrappers were called: not folded"
+    # a write through .data does not bump _version: explicit invalidation makes the next call refold
+    with torch.no_grad():
+        attn.to_q.lora_B["default"].weight.data.mul_(0.0)
+        attn.to_k.lora_B["default"].weight.data.mul_(0.0)
+    lora_fold.invalidate(attn)
+    want2, _, _ = O.shared_attn_processor_np(f(x), f(w_eff(attn.to_q)), f(w_eff(attn.to_k)), f(w_eff(attn.to_v)),
+                                             f(w_eff(attn.to_out[0])), f(attn.to_out[0].base_layer.bias.double().cpu()),
+                                             f(rk.float()), f(rv.float()), H, use_adain=True, train_input=True,
+                                             dtype=np.float64, return_probs=True)
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        got2 = attn(x.cuda(), ref_keys=[rk.cuda()], ref_values=[rv.cuda()])
+    assert np.abs(got2.float().cpu().numpy() - want2).max() <= 2 * tol * max(1.0, np.abs(want2).max())
+    # ... and the cache really was rebuilt: the new result sits on the new target, far from the old one
+    g2 = got2.float().cpu().numpy()
+    assert np.abs(g2 - want).max() > 3 * np.abs(g2 - want2).max()
+
+
+def test_harvest_zero_fill_waits_for_the_reference_forward_on_a_side_stream():
+    """with the reference UNet on a side stream and valid_indices < N, the zero fill must not run
+    before that forward has written K/V nor while its attention still reads them.  The side stream is made slow (a
+    long GEMM chain queued first), the harvest is called immediately, and the main stream consumes the lists."""
+    from instantrestore_amd.kv_harvest import enable_stream_overlap, harvest_reference_kv
+    kv_unet, unet = _hosts()
+    enable_stream_overlap(kv_unet)
+    B, N, S = 2, 3, 16
+    g = torch.Generator().manual_seed(3)
+    refs = torch.randn(B * N, 4, S, S, generator=g).cuda()
+    text = torch.randn(1, 77, 64, generator=g).cuda()
+    x = torch.randn(B, 4, S, S, generator=g).cuda()
+    valid = [3, 1]
+    big = torch.randn(4096, 4096, device="cuda")
+
+    def run(two_streams):
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream() if two_streams else cur
+        side.wait_stream(cur)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.cuda.stream(side):
+                if two_streams:
+                    t = big
+                    for _ in range(30):          # ~tens of ms of queued work ahead of the reference forward
+                        t = (t @ big) * 1e-3
+                kv_unet(refs, None, encoder_hidden_states=text.repeat(B * N, 1, 1))
+            keys, vals, events = harvest_reference_kv(kv_unet, N, valid, with_events=True)
+            y = unet(x, None, encoder_hidden_states=text.repeat(B, 1, 1),
+                     cross_attention_kwargs={"ref_keys": keys, "ref_values": vals, "ref_events": events if two_streams else None}).sample
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        return [k.clone() for k in keys], [v.clone() for v in vals], y
+
+    k1, v1, y1 = run(False)
+    for _ in range(2):
+        k2, v2, y2 = run(True)
+        for a, b in zip(k1 + v1, k2 + v2):
+            assert torch.equal(a, b)
+        assert torch.equal(y1, y2)
+    for k in k1:
+        assert float(k[1, 1:].abs().max()) == 0.0 and float(k[0].abs().min(dim=-1).values.max()) > 0.0
+
+
+def test_bf16_error_before_and_after_the_output_rounding():
+    """BASELINE.json's north_star asks for <= 1e-3 max-abs deviation.  For bf16 OUTPUTS of O(1) that is below the format's
+    own rounding step (half an ulp at 1.0 is 3.9e-3), so the statement has two halves, both measured here on N(0,1)
+    activations at the cfg-2 top layer class (L = 4096, N = 4, AdaIN, self segment): (a) the kernel's result BEFORE the
+    rounding (fp32 through IR_FLAG_OUT_F32) is within 1e-3 of the float64 oracle; (b) the bf16 result is within half a
+    bf16 ulp (+ (a)) of the oracle, i.e. it is the oracle's value rounded to bf16 up to (a)."""
+    from instantrestore_amd import ops
+    torch.manual_seed(0)
+    B, H, L, N = 1, 1, 4096, 4
+    C = H * 64
+    dt = torch.bfloat16
+    q, k, v = (torch.randn(B, L, C).to(dt) for _ in range(3))
+    rk, rv = torch.randn(B, N, L, C).to(dt), torch.randn(B, N, L, C).to(dt)
+    rows = torch.arange(0, L, 16)                    # every 16th query row against the full 20480 keys
+    f = lambda t: t.float().numpy().astype(np.float64)
+    ref = O.shared_attention_np(f(q[:, rows]), f(k), f(v), f(rk), f(rv), H, 0.125, True, True)
+    c = lambda t: t.cuda()
+    aff = ops.adain_stats(c(v), c(rv), heads=H)
+    kw = dict(heads=H, scale=0.125, include_self=True, adain=aff)
+    out32 = ops.shared_attention(c(q), c(k), c(v), c(rk), c(rv), out_dtype=torch.float32, **kw)
+    out16 = ops.shared_attention(c(q), c(k), c(v), c(rk), c(rv), **kw)
+    assert out32.dtype == torch.float32 and out16.dtype == dt
+    e32 = np.abs(out32[:, rows].cpu().numpy().astype(np.float64) - ref).max()
+    e16 = np.abs(out16[:, rows].float().cpu().numpy().astype(np.float64) - ref).max()
+    half_ulp = 2.0 ** -9 * 2.0 ** np.floor(np.log2(max(np.abs(ref).max(), 1e-30)))
+    print(f"\n[bf16 tolerance] max|O| {np.abs(ref).max():.3f}: before rounding {e32:.2e}, after {e16:.2e} (half ulp at max|O| {half_ulp:.2e})")
+    assert e32 <= 1e-3
+    assert e16 <= e32 + half_ulp * 1.0001
+    # and the 16-bit launch is the same arithmetic: rounding the fp32 result gives the bf16 result of the same kernel
+    ops.set_attn_variant(16)
+    try:
+        out16_sp = ops.shared_attention(c(q), c(k), c(v), c(rk), c(rv), **kw)
+    finally:
+        ops.set_attn_variant(0)
+    assert torch.equal(out32.to(dt), out16_sp)

@@ -16,6 +16,13 @@ Conv/ResNet/VAE stages of the UNets are stock MIOpen/hipBLASLt work outside the 
 (OUT OF SCOPE) and are NOT in the step; ``config.workload`` says so.
 ``value`` = identities (restored images) per second over all ranks = B_total / step time.
 
+Inputs are what the reference's caller hands the processors (inference/test.py:61-83): fp32 module weights, fp32
+token activations (LayerNorm output), ``torch.autocast`` to the 16-bit compute dtype - the cast to 16 bit is part of the
+step.  Next to the headline (eager, two HIP streams) the line carries, labelled, under ``config.extras``: the same step
+on one stream, the same step replayed from ONE hipGraph, the step with cached reference K/V, an
+end-to-end leg on the attention-topology host with the stage names of pix2pix_turbo.py:288-336, and the batch
+scatter / gather of SURVEY 8e over the process group (RCCL when N > 1).  None of them is ``value``.
+
 Contract: ``python bench.py --gpus N --steps K --warmup W``; for N > 1 launched by
 ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``; one rank per GPU,
 identities sharded across ranks (no data-path collective: they are independent), barrier +
@@ -49,7 +56,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(cfg, train_input, dev, seed):
+def build_workload(cfg, train_input, dev, seed, act_fp32=True):
     from face_replace.models.attn_processors import AttnProcessor, SharedAttnProcessor
     from instantrestore_amd.attention import Attention
     from instantrestore_amd.roofline import layer_classes
@@ -66,12 +73,13 @@ def build_workload(cfg, train_input, dev, seed):
                 with torch.no_grad():
                     for lin in (a.to_q, a.to_k, a.to_v, a.to_out[0]):
                         lin.weight.copy_(torch.randn(lin.weight.shape, generator=g) / C ** 0.5)
-                return a.to(dev, dtype)
+                return a.to(dev) if act_fp32 else a.to(dev, dtype)   # test.py:61-63: the model stays fp32 under autocast
             kv_attn = mk(AttnProcessor())
             main_attn = mk(SharedAttnProcessor(self_attn_idx=idx, use_adain=use_adain, train_input=train_input))
             # token activations entering the two attentions (LayerNorm output in the real UNet)
-            h_ref = torch.randn(B * N, L, C, generator=g).to(dev, dtype)
-            h_main = torch.randn(B, L, C, generator=g).to(dev, dtype)
+            act = torch.float32 if act_fp32 else dtype
+            h_ref = torch.randn(B * N, L, C, generator=g).to(dev, act)
+            h_main = torch.randn(B, L, C, generator=g).to(dev, act)
             layers.append(dict(L=L, C=C, H=H, kv_attn=kv_attn, main_attn=main_attn, h_ref=h_ref, h_main=h_main))
             idx += 1
     return layers, (B, N, px, dtype, use_adain)
@@ -80,13 +88,27 @@ def build_workload(cfg, train_input, dev, seed):
 _REF_STREAM = {}
 
 
-def hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False):
+_AUTOCAST = {"dtype": None}   # set by main(): the 16-bit compute dtype the step autocasts to (None: inputs already 16 bit)
+
+
+def hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached_kv=None):
+    if _AUTOCAST["dtype"] is None:
+        return _hot_path_step(layers, B, N, ref_early_exit, two_streams, cached_kv)
+    with torch.autocast("cuda", dtype=_AUTOCAST["dtype"]):
+        return _hot_path_step(layers, B, N, ref_early_exit, two_streams, cached_kv)
+
+
+def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached_kv=None):
     """one pass: K/V capture -> harvest -> shared attention.  Returns the 9 outputs.
+    ``cached_kv`` = (keys, values): the reference branch is skipped (per-identity K/V cache).
 
     ``two_streams``: the reference UNet's layers run on their own HIP stream and shared layer i waits only
     for the event of capture layer i (it reads nothing else), so the small layer classes - which cannot
     fill 256 CUs on their own - overlap with the other UNet's kernels.  Same kernels, same work."""
     from instantrestore_amd.attn_processors import ReferenceCaptureComplete
+    if cached_kv is not None:
+        keys, vals = cached_kv
+        return [ly["main_attn"](ly["h_main"], ref_keys=keys, ref_values=vals) for ly in layers]
     cur = torch.cuda.current_stream()
     ref_stream = cur
     if two_streams:
@@ -133,9 +155,11 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
     L, C, H = ly["L"], ly["C"], ly["H"]
     a = ly["main_attn"]
     with torch.no_grad():
-        q, k, v = a.to_q(ly["h_main"]), a.to_k(ly["h_main"]), a.to_v(ly["h_main"])
-        kr = layers[-1]["kv_attn"].to_k(ly["h_ref"]).reshape(B, N, L, C)
-        vr = layers[-1]["kv_attn"].to_v(ly["h_ref"]).reshape(B, N, L, C)
+        hm, hr = ly["h_main"].to(dtype), ly["h_ref"].to(dtype)
+        lin = lambda m, x: torch.nn.functional.linear(x, m.weight.to(dtype))
+        q, k, v = lin(a.to_q, hm), lin(a.to_k, hm), lin(a.to_v, hm)
+        kr = lin(layers[-1]["kv_attn"].to_k, hr).reshape(B, N, L, C)
+        vr = lin(layers[-1]["kv_attn"].to_v, hr).reshape(B, N, L, C)
         aff = ops.adain_stats(v, vr, heads=H) if use_adain else None
         ops.time_shared_attention(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input, adain=aff, iters=3)
         ms = ops.time_shared_attention(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input,
@@ -156,19 +180,26 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
         "algorithmic_mb_per_launch": round(attn_bytes(B, L, lkv, C) / 1e6, 2),
         # HBM bytes per launch from a separate rocprofv3 --pmc pass of this kernel at this shape
-        # (tools/pmc_attn.sh -> profiles/r1_pmc_shared_attn.txt); FETCH_SIZE doubled per the
+        # (tools/pmc_attn.sh -> profiles/r2_pmc_shared_attn.txt, r1_... if absent); FETCH_SIZE doubled per the
         # gfx950 correction of MI355X_MICROARCH.md.  null if the profile is not for this shape.
         "traffic": _pmc_traffic_bytes() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
-        "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_pmc_shared_attn.txt)",
+        "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)" % _pmc_profile_name(),
         "power_note": "this kernel runs at the 1400 W board cap on random data (profiles/r1_power_probe.txt): "
                       "sustained shader clock 2.1-2.2 GHz against the 2.4 GHz the peak assumes; an MFMA-only stream of the same "
                       "instruction holds 1.96 PFLOP/s on random operands under that cap (profiles/r1_ubench_mfma_power.txt)",
     }
 
 
+def _pmc_profile_name():
+    for name in ("r2_pmc_shared_attn.txt", "r1_pmc_shared_attn.txt"):
+        if os.path.exists(os.path.join(REPO, "profiles", name)):
+            return "profiles/" + name
+    return "no committed PMC profile"
+
+
 def _pmc_traffic_bytes():
     import ast
-    path = os.path.join(REPO, "profiles", "r1_pmc_shared_attn.txt")
+    path = os.path.join(REPO, _pmc_profile_name())
     try:
         vals = {}
         for line in open(path):
@@ -180,16 +211,17 @@ def _pmc_traffic_bytes():
         return None
 
 
-def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=25.0):
+def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=28.0, reps=3):
     """oracle port (torch-CPU fp32, the reference's operator sequence) on the host cores: one
-    identity through the same 9+9 layers, bounded to ~budget_s of CPU work."""
+    identity through the same 9+9 layers; per layer class one warm-up and the median of ``reps`` timed
+    passes, bounded to ~budget_s of CPU work (fewer repetitions on a slow host, stated in `sample`)."""
     from instantrestore_amd.roofline import layer_classes
     from oracle import shared_attn_oracle as O
 
     torch.manual_seed(seed)
     cores = torch.get_num_threads()
     t_total, done_layers, n_layers = 0.0, 0, 0
-    per_class = []
+    per_class, reps_done = [], []
     for (L, C, H) in layer_classes(px):
         n_layers += 3
         if t_total > budget_s:
@@ -198,13 +230,22 @@ def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=25.0):
         w = [torch.randn(C, C) / C ** 0.5 for _ in range(4)]
         bo = torch.zeros(C)
         h_ref, h_main = torch.randn(N, L, C), torch.randn(1, L, C)
-        t0 = time.perf_counter()
-        # K/V capture: plain attention over the N reference token sets
-        O.shared_attn_processor_port(h_ref, w[0], w[1], w[2], w[3], bo, None, None, H)
-        kr = torch.nn.functional.linear(h_ref, w[1]).reshape(1, N, L, C)
-        vr = torch.nn.functional.linear(h_ref, w[2]).reshape(1, N, L, C)
-        O.shared_attn_processor_port(h_main, w[0], w[1], w[2], w[3], bo, kr, vr, H, use_adain, train_input)
-        dt = time.perf_counter() - t0
+        def one_pass():
+            t0 = time.perf_counter()
+            # K/V capture: plain attention over the N reference token sets
+            O.shared_attn_processor_port(h_ref, w[0], w[1], w[2], w[3], bo, None, None, H)
+            kr = torch.nn.functional.linear(h_ref, w[1]).reshape(1, N, L, C)
+            vr = torch.nn.functional.linear(h_ref, w[2]).reshape(1, N, L, C)
+            O.shared_attn_processor_port(h_main, w[0], w[1], w[2], w[3], bo, kr, vr, H, use_adain, train_input)
+            return time.perf_counter() - t0
+        warm = one_pass()
+        times = []
+        for _ in range(reps):
+            if times and t_total + 3 * sorted(times)[len(times) // 2] + sum(times) + warm > budget_s:
+                break
+            times.append(one_pass())
+        dt = sorted(times)[len(times) // 2]
+        reps_done.append(len(times))
         per_class.append(dt)
         t_total += 3 * dt  # three identical layers per class: time one, count three
         done_layers += 3
@@ -216,9 +257,145 @@ def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=25.0):
         "cores": cores,
         "kind": "port",
         "sample": "1 identity, %d refs, %d px, fp32 torch-CPU port of the reference operator sequence "
-                  "(oracle/shared_attn_oracle.py), one layer per class timed and counted x3; seconds per class: %s"
-                  % (N, px, [None if t is None else round(t, 3) for t in per_class]),
+                  "(oracle/shared_attn_oracle.py), %s; one layer per class timed (1 warm-up + median of %s passes) and "
+                  "counted x3; seconds per class: %s"
+                  % (N, px, torch.__config__.parallel_info().split("\n")[1].strip(), reps_done,
+                     [None if t is None else round(t, 3) for t in per_class]),
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# labelled extras next to the headline (never `value`)
+# ---------------------------------------------------------------------------------------------------------------------
+def _time_steps(fn, steps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def extra_graph(layers, B, N, steps):
+    """the whole two-stream step captured in ONE hipGraph and replayed: same launches, same work, no CPU launch gaps"""
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    saved = dict(_REF_STREAM)
+    with torch.cuda.stream(s):
+        _REF_STREAM.clear()
+        hot_path_step(layers, B, N, False, True)     # side stream + per-stream workspaces exist before the capture
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            gouts = hot_path_step(layers, B, N, False, True)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        g.replay()
+    sec = _time_steps(g.replay, steps)
+    ref = hot_path_step(layers, B, N, False, True)
+    torch.cuda.synchronize()
+    same = all(torch.equal(a, b) for a, b in zip(ref, gouts))
+    _REF_STREAM.clear()
+    _REF_STREAM.update(saved)
+    return sec, same
+
+
+def extra_e2e(B, N, px, dtype, steps, dev):
+    """End-to-end leg on the attention-topology host (instantrestore_amd/unet_host.py: SD-Turbo's 32 attention
+    processors on both UNets with the real widths; conv/ResNet bodies, VAE and caption encoder are STAND-INS, SURVEY
+    section 2 puts them out of scope), with the reference's own stage names (pix2pix_turbo.py:288-336) + the caller's
+    pre/post-processing (test.py:54-59,139).  Stage times from HIP events on one stream."""
+    from types import SimpleNamespace
+    import __graft_entry__ as ge
+    from face_replace.models.attn_processors import register_attention_processor, register_attention_processor_kv_unet
+    from instantrestore_amd import ops
+    from instantrestore_amd.kv_harvest import get_conditioning_keys_values
+    from instantrestore_amd.preprocess import LanczosPreprocessor
+    from instantrestore_amd.unet_host import AttnTopologyUNet
+    sys.path.insert(0, os.path.join(REPO, "examples"))
+    from synthetic_inference import StandInVAE
+
+    cfg = SimpleNamespace(use_adain=True, train_input=True, condition_on_face_embeds=False)
+    original_unet, unet = AttnTopologyUNet(seed=1).to(dev), AttnTopologyUNet(seed=2).to(dev)
+    ge.register_attention_processor_kv_unet_default(original_unet, cfg)
+    register_attention_processor_kv_unet(original_unet)
+    register_attention_processor(unet, cfg)
+    vae = StandInVAE().to(dev)
+    caption = torch.randn(1, 77, 1024, device=dev)
+    gen = torch.Generator().manual_seed(0)
+    imgs = [torch.randint(0, 256, (px, px, 3), generator=gen, dtype=torch.uint8).to(dev) for _ in range(B + B * N)]
+    pre = LanczosPreprocessor(px, dtype)
+    names = ["Preprocessing (uint8 -> [-1,1], device)", "VAE Encoding (stand-in)", "Get Keys and Values",
+             "UNet", "Post-processing + VAE Decode (stand-in) + tensor2im"]
+
+    def one(record=None):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        ev[0].record()
+        batch = pre(imgs)
+        x, cond = batch[:B], batch[B:]
+        ev[1].record()
+        zx, zc = vae.encode(x), vae.encode(cond)
+        ev[2].record()
+        keys, vals = get_conditioning_keys_values(original_unet, zc, None, caption.expand(B * N, -1, -1), N, [N] * B)
+        ev[3].record()
+        z = unet(zx, None, encoder_hidden_states=caption.expand(B, -1, -1),
+                 cross_attention_kwargs={"ref_keys": keys, "ref_values": vals}).sample
+        ev[4].record()
+        out = ops.tensor2im_u8(vae.decode(z))
+        ev[5].record()
+        if record is not None:
+            record.append(ev)
+        return out
+
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        for _ in range(2):
+            out = one()
+        rec = []
+        sec = _time_steps(lambda: one(rec), steps)
+    torch.cuda.synchronize()
+    stage_ms = [round(sum(e[i].elapsed_time(e[i + 1]) for e in rec) / len(rec), 3) for i in range(len(names))]
+    assert out.shape == (B, px, px, 3)
+    del original_unet, unet
+    return {"images_per_s": round(B / sec, 2), "ms_per_batch": round(sec * 1e3, 3), "identities": B,
+            "stages_ms": dict(zip(names, stage_ms)),
+            "note": "attention-topology host: all 32 attention processors of both UNets at SD-Turbo widths run the HIP "
+                    "path; conv/ResNet bodies, VAE and caption encoder are stand-ins (out of scope) - not end-to-end "
+                    "InstantRestore throughput"}
+
+
+def extra_scatter_gather(B_local, N, px, world, rank, dev, backend):
+    """the batch scatter (degraded + references, fp16) and the output gather as grouped point-to-point
+    transfers over the process group - RCCL send/recv when N > 1 - outside the headline timing."""
+    from instantrestore_amd import sharding
+    total = B_local * world
+    dt = torch.float16
+    if backend != "nccl" and world > 1:
+        tdev = torch.device("cpu")
+    else:
+        tdev = dev
+    deg = torch.zeros(total, 3, px, px, dtype=dt, device=tdev) if rank == 0 else None
+    refs = torch.zeros(total, N, 3, px, px, dtype=dt, device=tdev) if rank == 0 else None
+    step = lambda d, r: d * 1.0    # stands for the restoration of the shard: (b,3,px,px) -> (b,3,px,px)
+    for _ in range(2):
+        sharding.run_sharded(step, deg, refs, total, (3, px, px), N, dt, tdev)
+    if tdev.type == "cuda":
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        out = sharding.run_sharded(step, deg, refs, total, (3, px, px), N, dt, tdev)
+    if tdev.type == "cuda":
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    ok = (out is not None and tuple(out.shape) == (total, 3, px, px)) if rank == 0 else out is None or world == 1
+    return {"scatter_gather_ms": round(ms, 3), "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+            "backend": backend if world > 1 else "none (one rank: slicing only)",
+            "bytes_per_identity": (1 + N) * 3 * px * px * 2 + 3 * px * px * 2, "ok": bool(ok)}
 
 
 def main():
@@ -233,6 +410,11 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B (ir_set_attn_variant); 0 = default")
     ap.add_argument("--two-streams", type=int, default=1,
                     help="1: reference-UNet layers on their own HIP stream, shared layer i waits for capture layer i only")
+    ap.add_argument("--act-dtype", default="fp32", choices=["fp32", "lowp"],
+                    help="fp32 (default): fp32 weights and token activations under torch.autocast, as inference/test.py:61-83 "
+                         "runs the model (the 16-bit cast is part of the step); lowp: everything pre-cast to the 16-bit dtype")
+    ap.add_argument("--no-extras", action="store_true", help="skip the labelled extra legs (one stream, hipGraph, cached "
+                                                              "K/V, end-to-end host, scatter/gather)")
     ap.add_argument("--ref-early-exit", action="store_true",
                     help="stop the reference UNet after the K/V projections of its last capturing layer (its output is "
                          "discarded by the inference caller); off for the headline number")
@@ -261,7 +443,9 @@ def main():
     if args.variant:
         from instantrestore_amd import ops as _ops
         _ops.set_attn_variant(args.variant)
-    layers, (B, N, px, dtype, use_adain) = build_workload(args.config, train_input, dev, seed=1234 + rank)
+    act_fp32 = args.act_dtype == "fp32"
+    layers, (B, N, px, dtype, use_adain) = build_workload(args.config, train_input, dev, seed=1234 + rank, act_fp32=act_fp32)
+    _AUTOCAST["dtype"] = dtype if act_fp32 else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -323,6 +507,45 @@ def main():
                                                "note": "in the headline run: includes time shared with the other stream's kernels"}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(N, px, train_input, use_adain, seed=99)
+    extras = None
+    if not args.no_extras:
+        extras = {}
+        if rank == 0:
+            with torch.no_grad():
+                sec1 = _time_steps(lambda: hot_path_step(layers, B, N, args.ref_early_exit, False), args.steps)
+                extras["one_stream"] = {"images_per_s": round(B / sec1, 2), "ms_per_step": round(sec1 * 1e3, 4),
+                                        "note": "same step, both UNets on one HIP stream (the reference's own schedule)"}
+                try:
+                    secg, same = extra_graph(layers, B, N, args.steps)
+                    extras["hip_graph"] = {"images_per_s": round(B / secg, 2), "ms_per_step": round(secg * 1e3, 4),
+                                           "bit_identical_to_eager": bool(same),
+                                           "note": "the same two-stream step captured once in ONE hipGraph and replayed: same "
+                                                   "launches, same work, no launch gaps"}
+                except Exception as e:   # capture is an extra: never lose the headline over it
+                    extras["hip_graph"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                keys, vals = [], []
+                for ly in layers:   # resident reference K/V of the batch's identities (what ReferenceKVCache.assemble returns)
+                    with torch.autocast("cuda", dtype=dtype):
+                        ly["kv_attn"](ly["h_ref"])
+                    p = ly["kv_attn"].processor
+                    keys.append(p.keys.reshape(-1, N, *p.keys.shape[1:]).clone())
+                    vals.append(p.values.reshape(-1, N, *p.values.shape[1:]).clone())
+                    p.reset()
+                secc = _time_steps(lambda: hot_path_step(layers, B, N, cached_kv=(keys, vals)), args.steps)
+                extras["kv_cached"] = {"images_per_s": round(B / secc, 2), "ms_per_step": round(secc * 1e3, 4),
+                                       "note": "reference K/V served from the per-identity cache (SURVEY 8f rank 2): only the nine "
+                                               "shared layers run; valid when the references of an identity repeat across frames"}
+                del keys, vals
+                if args.config != "cfg5":
+                    try:
+                        extras["e2e_topology_host"] = extra_e2e(B, N, px, dtype, max(2, args.steps // 2), dev)
+                    except Exception as e:
+                        extras["e2e_topology_host"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            sg = extra_scatter_gather(B, N, px, world, rank, dev, backend)
+        except Exception as e:
+            sg = {"error": "%s: %s" % (type(e).__name__, e)}
+        extras["scatter_gather"] = sg
     if world > 1:
         dist.barrier()
 
@@ -332,6 +555,9 @@ def main():
         total_ids = B * world
         line = {
             "metric": "restored images/sec @512px, 4 refs, single-step; 1/2/4/8 MI355X",
+            "metric_note": "one step = one pass of the HOT PATH only (attention path of both UNets, SURVEY 8a a-1..a-4): "
+                           "identities pushed through it per second, NOT end-to-end restoration throughput (conv/ResNet/VAE "
+                           "stages are out of scope and not in the step); eager launches, two HIP streams",
             "value": round(total_ids / (elapsed / args.steps), 3),
             "unit": "images/s",
             "n_gpus": world,
@@ -350,6 +576,10 @@ def main():
                             "and not in the step" % args.config,
                 "identities_per_gpu": B, "global_batch": total_ids, "refs": N, "px": px,
                 "use_adain": use_adain, "train_input": train_input, "ref_early_exit": bool(args.ref_early_exit), "two_streams": bool(args.two_streams), "parallelism": "dp%d (independent identities)" % world,
+                "activations": "fp32 under torch.autocast (test.py:61-83)" if act_fp32 else "pre-cast to the 16-bit dtype",
+                "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                "scatter_gather_ms": None if not extras else extras.get("scatter_gather", {}).get("scatter_gather_ms"),
+                "extras": extras,
                 **{k: round(v, 1) for k, v in summary(N, train_input, px).items()},
             },
             "roofline": roof,

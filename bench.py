@@ -155,16 +155,22 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
     L, C, H = ly["L"], ly["C"], ly["H"]
     a = ly["main_attn"]
     with torch.no_grad():
+        from instantrestore_amd import attn_processors as ap
         hm, hr = ly["h_main"].to(dtype), ly["h_ref"].to(dtype)
         lin = lambda m, x: torch.nn.functional.linear(x, m.weight.to(dtype))
-        q, k, v = lin(a.to_q, hm), lin(a.to_k, hm), lin(a.to_v, hm)
+        k, v = lin(a.to_k, hm), lin(a.to_v, hm)
+        # q exactly as the processor produces it at this shape: through the library's own fused-projection GEMM it
+        # leaves the epilogue pre-scaled (attn_processors._project_qkv) and the attention runs its pre-scaled-Q form
+        wq = a.to_q.weight.to(dtype)
+        presc = bool(ap.PRESCALE_Q and ap._own_gemm(hm, torch.cat([wq, wq, wq], 0), None))
+        q = ops.linear(hm, wq, None, scale_cols=C, col_scale=0.125 * ap.LOG2E) if presc else lin(a.to_q, hm)
         kr = lin(layers[-1]["kv_attn"].to_k, hr).reshape(B, N, L, C)
         vr = lin(layers[-1]["kv_attn"].to_v, hr).reshape(B, N, L, C)
         aff = ops.adain_stats(v, vr, heads=H) if use_adain else None
-        ops.time_shared_attention(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input, adain=aff, iters=3)
-        ms = ops.time_shared_attention(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input,
-                                       adain=aff, iters=20)
-        kname = ops.shared_attention_kernel_name(q, k, v, kr, vr, heads=H, scale=0.125, include_self=train_input, adain=aff)
+        kw = dict(heads=H, scale=0.125, include_self=train_input, adain=aff, q_prescaled=presc)
+        ops.time_shared_attention(q, k, v, kr, vr, iters=3, **kw)
+        ms = ops.time_shared_attention(q, k, v, kr, vr, iters=20, **kw)
+        kname = ops.shared_attention_kernel_name(q, k, v, kr, vr, **kw)
     lkv = (N + int(train_input)) * L
     flops = attn_flops(B, L, lkv, C)
     tf = flops / (ms * 1e-3) / 1e12

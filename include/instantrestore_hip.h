@@ -284,6 +284,12 @@ int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32
  */
 int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                   int64_t w_ld, const void* bias, void* y, int64_t y_ld, void* stream);
+/* The same with output columns [0, scale_cols) multiplied by col_scale in the fp32 accumulator, before the one rounding
+ * (y = acc * col_scale + bias there): the fused q/k/v projection hands the attention kernel Q * scale * log2(e)
+ * (IR_FLAG_Q_PRESCALED) at no extra rounding.  scale_cols % 32 == 0. */
+int ir_linear_fwd_scaled(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                         int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
+                         void* stream);
 
 /* library identity / diagnostics */
 int ir_abi_version(void);                  /* == IR_ABI_VERSION */

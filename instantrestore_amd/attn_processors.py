@@ -104,6 +104,11 @@ def _autocast_or(weight: torch.Tensor, x: torch.Tensor) -> torch.dtype:
 _SKINNY_MIN_WORK = 1 << 24   # rows * out_features below which the vendor GEMM is as fast (tools/gpu_gemm_probe.py)
 
 
+def _own_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
+    rows = x.numel() // x.shape[-1]
+    return bool(rows * w.shape[0] >= _SKINNY_MIN_WORK and _ops.linear_supported(x, w, bias))
+
+
 def _linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     """``F.linear`` with the large K <= 320 and K = 640 shapes (64x64- and 32x32-token layer classes) routed
     to the X-stationary HIP GEMM (``ir_linear_fwd``, 1.5-1.6x the vendor kernel there); every other shape is a
@@ -114,8 +119,13 @@ def _linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> t
     return torch.nn.functional.linear(x, w, bias)
 
 
+LOG2E = 1.4426950408889634
+PRESCALE_Q = True   # own fused q/k/v GEMM: q leaves its epilogue as Q * attn.scale * log2(e) (still one rounding)
+
+
 def _project_qkv(attn, st: _Prepared):
-    """``to_q`` / ``to_k`` / ``to_v`` of the reference (attn_processors.py:222-230).
+    """``to_q`` / ``to_k`` / ``to_v`` of the reference (attn_processors.py:222-230).  Returns
+    ``(q, k, v, q_prescaled)``.
 
     Self-attention whose three projections are bias-free linear maps of equal shape - plain
     ``nn.Linear`` or peft LoRA wrappers in inference state (``lora_fold``) - runs them as ONE
@@ -125,21 +135,27 @@ def _project_qkv(attn, st: _Prepared):
     projections (each output column is the same dot product); for LoRA wrappers the adapter is
     merged exactly as peft's ``merge_and_unload`` does.  Anything else - cross attention, biased
     projections, active dropout, DoRA, training - takes the three module calls like the
-    reference."""
+    reference.
+
+    Pre-scaled Q: when the fused GEMM is this library's own kernel (``ir_linear_fwd_scaled``), the q third of its
+    output is multiplied by ``attn.scale * log2(e)`` in the fp32 accumulator, before the one rounding to 16 bit every
+    projection output gets anyway.  The attention kernel is told so (``IR_FLAG_Q_PRESCALED``) and drops the
+    multiply-add per score.  Shapes that go to the vendor GEMM keep the plain q."""
     src = _kv_source(attn, st)
     tq, tk, tv = attn.to_q, attn.to_k, attn.to_v
     if st.encoder is not None or torch.is_grad_enabled():
-        return tq(st.hidden), tk(src), tv(src)
+        return tq(st.hidden), tk(src), tv(src), False
     effs = [_lora.effective_linear(m) for m in (tq, tk, tv)]
     if any(e is None or e[0].bias is not None for e in effs) or \
             not (effs[0][0].weight.shape == effs[1][0].weight.shape == effs[2][0].weight.shape):
-        return tq(st.hidden), tk(src), tv(src)
+        return tq(st.hidden), tk(src), tv(src), False
     dtype = _autocast_or(effs[0][0].weight, st.hidden)
     w = _lora.cached_weight(attn, "_ir_qkv_cache", (tq, tk, tv), dtype)
     x = st.hidden if st.hidden.dtype == dtype else st.hidden.to(dtype)
-    qkv = _linear(x, w, None)
     c = w.shape[0] // 3
-    return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:]
+    presc = bool(PRESCALE_Q and c % 32 == 0 and _own_gemm(x, w, None))
+    qkv = _ops.linear(x, w, None, scale_cols=c, col_scale=float(attn.scale) * LOG2E) if presc else _linear(x, w, None)
+    return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], presc
 
 
 def _project_kv_only(attn, st: _Prepared):
@@ -235,11 +251,12 @@ class AttnProcessor(nn.Module):
             self.keys, self.values = _project_kv_only(attn, st)
             self._mark_ready()
             raise ReferenceCaptureComplete()
-        query, key, value = _project_qkv(attn, st)
+        query, key, value, presc = _project_qkv(attn, st)
         self.keys, self.values = key, value  # consumed in place by the shared layers: no copies
         self._mark_ready()
         _same_16bit(query, key, value)
-        tokens = _ops.shared_attention(query, key, value, heads=attn.heads, scale=attn.scale, include_self=True)
+        kw = {"q_prescaled": True} if presc else {}
+        tokens = _ops.shared_attention(query, key, value, heads=attn.heads, scale=attn.scale, include_self=True, **kw)
         return _epilogue(attn, st, tokens)
 
 
@@ -299,7 +316,7 @@ class SharedAttnProcessor(nn.Module):
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                 ref_keys=None, ref_values=None, ref_events=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
-        query, key, value = _project_qkv(attn, st)
+        query, key, value, presc = _project_qkv(attn, st)
 
         ref_k = ref_v = None
         include_self = True
@@ -321,12 +338,15 @@ class SharedAttnProcessor(nn.Module):
         _same_16bit(query, key, value, ref_k, ref_v)
 
         want_probs = bool(self.save_self_attentions)
+        kw = {"q_prescaled": True} if presc else {}
         res = _ops.shared_attention(query, key, value, ref_k, ref_v, heads=attn.heads, scale=attn.scale,
-                                    include_self=include_self, adain=affine, return_lse=want_probs)
+                                    include_self=include_self, adain=affine, return_lse=want_probs, **kw)
         if want_probs:
             tokens, lse = res
-            # (B, H, L, Lkv), columns [self?] ++ ref0 ++ ... ++ refN-1, in the compute dtype
-            self.attention_probs = _ops.attn_probs(query, key, ref_k, lse, heads=attn.heads, scale=attn.scale,
+            # (B, H, L, Lkv), columns [self?] ++ ref0 ++ ... ++ refN-1, in the compute dtype.  A pre-scaled query
+            # already carries scale * log2(e): its scores are exponents, ln 2 turns them into the logits of the LSE
+            self.attention_probs = _ops.attn_probs(query, key, ref_k, lse, heads=attn.heads,
+                                                   scale=0.6931471805599453 if presc else attn.scale,
                                                    include_self=include_self)
         else:
             tokens = res

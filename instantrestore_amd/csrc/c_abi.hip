@@ -65,8 +65,11 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->include_self = inc ? 1 : 0;
   p->q_prescaled = (a->flags & IR_FLAG_Q_PRESCALED) ? 1 : 0;
   p->out_f32 = (a->flags & IR_FLAG_OUT_F32) ? 1 : 0;
-  if ((p->q_prescaled || p->out_f32) && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_SP64)
-    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED / IR_FLAG_OUT_F32 are implemented by the default (SP64) kernel only");
+  if (p->out_f32 && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_SP64)
+    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_OUT_F32 is implemented by the SP64 kernel only");
+  if (p->q_prescaled && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_SP64 && a->tuning != IR_TUNE_W64X8 &&
+      a->tuning != IR_TUNE_PIPE32_PRESCALE_Q)
+    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8, PIPE32_PRESCALE_Q and SP64 kernels only");
   p->tiles_self = inc ? (a->len_self + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->tiles_ref = a->n_refs > 0 ? (a->len_ref + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->ntiles = p->tiles_self + a->n_refs * p->tiles_ref;
@@ -98,11 +101,14 @@ const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
   const int v = args->tuning & 31;
   const bool fold = p.aa != nullptr;
   switch (v) {
-    case 0: return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>")
+    case 0: if (p.q_prescaled) return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, pre-scaled Q (reference through the MFMA C operand), AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, pre-scaled Q (reference through the MFMA C operand)>")
+                                                             : "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q>";
+            return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>")
                                              : (fold ? "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK, AdaIN fold>" : "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK>");
     case 12: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves>";
     case 13: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>";
     case 11: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q>";
+    case 16: return "shared_attn_fwd_sp_kernel<64 rows/wave, one wave per SIMD, software-pipelined>";
     case 10: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max>";
     case 8: return "shared_attn_fwd_pp_kernel";
     default: return "shared_attn_fwd (tuning variant)";
@@ -346,6 +352,13 @@ int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32
 
 int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                   int64_t w_ld, const void* bias, void* y, int64_t y_ld, void* stream) {
+  return ir_linear_fwd_scaled(dtype, m, n, k, x, x_ld, w, w_ld, bias, y, y_ld, 0, 1.0f, stream);
+}
+
+int ir_linear_fwd_scaled(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                         int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
+                         void* stream) {
+  if (scale_cols < 0 || scale_cols > n || (scale_cols % 32) != 0) return fail(IR_ERR_INVALID_ARG, "scale_cols %d: a multiple of 32 in [0, N]", scale_cols);
   if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d: fp16 (0) / bf16 (1)", dtype);
   if (!x || !w || !y) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
   if (m <= 0 || n <= 0 || k <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
@@ -361,6 +374,7 @@ int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x,
   LinearKParams p;
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.x_ld = x_ld; p.w_ld = w_ld; p.y_ld = y_ld;
   p.M = (int32_t)m; p.N = n; p.K = k; p.nsplit = 1;
+  p.scale_cols = scale_cols; p.col_scale = col_scale;
   const hipError_t e = ir_launch_linear_skinny(p, dtype, (hipStream_t)stream);
   if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "linear launch: %s", hipGetErrorString(e));
   return IR_OK;

@@ -85,11 +85,12 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   // the 64 contiguous bytes of a row (16 B each, 16 rows per store instruction).
   unsigned char* tb = tbuf + wid * (64 * TPITCH);
   auto stage_block = [&](const f32x16& acc, int rbase, int n0) {
+    const float cs = n0 < p.scale_cols ? p.col_scale : 1.0f;   // leading columns scaled in fp32 before the one rounding
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f32x4 f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) f[i] = acc[4 * g + i];
+      for (int i = 0; i < 4; ++i) f[i] = acc[4 * g + i] * cs;
       if (p.bias != nullptr) {
         const v4 bv = *(const v4*)(sbias + (n0 - c_begin * NCH) + 8 * g + 4 * hi);
 #pragma unroll
@@ -267,6 +268,7 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
     };
     // the staged rows of block A (bytes 0 .. 2559 of the tile) cover the partial quads 0-2 of A; those of block B
     // (2560 .. 5119) cover A's quad 3 and B's quad 0 (4096 ..): read what a write is about to cover first
+    const float cs = n0 < p.scale_cols ? p.col_scale : 1.0f;   // leading columns scaled in fp32 before the one rounding
     f32x4 pa[4], pb0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) pa[g] = rd(g);
@@ -276,7 +278,7 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
       const f32x4 bz = bias4(g);
       f32x4 fa;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = a[4 * g + i] + pa[g][i] + bz[i];
+      for (int i = 0; i < 4; ++i) fa[i] = (a[4 * g + i] + pa[g][i]) * cs + bz[i];
       *(v4*)(r + lq * TPITCH + (8 * g + 4 * hi) * 2) = __builtin_convertvector(fa, v4);
     }
     f32x4 pb[4];
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
       const f32x4 bz = bias4(g);
       f32x4 fb;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fb[i] = b[4 * g + i] + pb[g][i] + bz[i];
+      for (int i = 0; i < 4; ++i) fb[i] = (b[4 * g + i] + pb[g][i]) * cs + bz[i];
       *(v4*)(r + (32 + lq) * TPITCH + (8 * g + 4 * hi) * 2) = __builtin_convertvector(fb, v4);
     }
   };

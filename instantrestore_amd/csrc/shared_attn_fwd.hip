@@ -453,7 +453,14 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   }
 #endif
   const int base = variant & 31;
-  if (p.q_prescaled || p.out_f32) return ir_launch_shared_attn_fwd_sp(p, dtype, s);   // implemented there only
+  // fp32 output: the one-wave-per-SIMD kernel only; pre-scaled Q: the 64-row kernel's QS instantiation where the default
+  // rule (or IR_TUNE_W64X8) takes that kernel, the 32-row kernel's reference-through-C form for every other shape
+  if (p.out_f32) return ir_launch_shared_attn_fwd_sp(p, dtype, s);
+  if (p.q_prescaled) {
+    if ((base == 0 && ir_attn_default_is_w64(p)) || base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
+    if (base == 16) return ir_launch_shared_attn_fwd_sp(p, dtype, s);
+    return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);   // the 32-row kernel's pre-scaled-Q form, minus its own Q rounding
+  }
   switch (base) {
     case 16: return ir_launch_shared_attn_fwd_sp(p, dtype, s);
     case 0:

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
   // matrix pipe already in the exp2 domain and - with the running reference fed through the C operand
   // of the first QK^T MFMA - already shifted: no per-score scale-and-subtract on the VALU.
   constexpr bool PRESC = (ABL & 2048) != 0;
-  if (PRESC) {
+  if (PRESC && !p.q_prescaled) {   // IR_FLAG_Q_PRESCALED: the projection already applied the factor (one rounding in all)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
       qf[ks] = __builtin_convertvector(__builtin_convertvector(qf[ks], f32x8) * p.scale_log2, v8);

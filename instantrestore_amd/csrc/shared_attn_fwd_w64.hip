@@ -18,6 +18,7 @@ constexpr int KVB = IR_KV_TILE;
 constexpr int TILE_BYTES = KVB * 64 * 2;  // 8 KiB
 
 struct RowBlock {
+  f32x16 nm;         // QS: minus the running reference in all 16 registers - the C operand of a tile's first QK^T MFMAs
   f32x16 o0, o1;     // O^T accumulators (d = 32*db + crow(r,hi), column = query row)
   f32x2 la, lb;      // partial row sums
   float m_run;       // running (lazy) max of the raw scores
@@ -37,7 +38,13 @@ struct RowBlock {
 // 2080 -> 1650 ns per tile pair for this instruction mix).  K/V ring of 4 pairs: pair u is read in phases
 // 2u .. 2u+3 (K(u) by QK^T(u) in M(u), V(u) by PV(u) in M(u+1), each phase twice: once per wave group); every
 // wave issues its share of pair j+2 at the start of its M(j) and waits for pair j+1 at the end of it.
-template <typename T, bool FOLD, int NW = 4, bool PP = false>
+// QS (IR_FLAG_Q_PRESCALED, 8 waves): Q arrives as Q * scale * log2(e) (the fused q/k/v projection folds the factor into
+// its weights), so the scores leave the matrix pipe as exponents; the running reference enters through the C operand of
+// the first QK^T MFMAs of a tile (a 16-register block per row block, rewritten only when the lazy rule moves the
+// reference) and the scale-and-subtract multiply-add per score disappears (64 of ~236 VALU instructions per wave and
+// tile).  The two reference blocks take the registers of the Q fragments, which move to a wave-private LDS copy and
+// are read per tile next to the K fragments (the arrangement of the ping-pong build).
+template <typename T, bool FOLD, int NW = 4, bool PP = false, bool QS = false>
 __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
@@ -53,9 +60,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   constexpr int K_OFF = 0, V_OFF = RING * TILE_BYTES;
   // PP: the ring (64 KiB) and a wave-private copy of the Q fragments (8 KiB per wave; the rotated loop keeps the
   // next tile's scores alive across the iteration and has no registers left for them) exceed the static limit
-  __shared__ __attribute__((aligned(16))) unsigned char smem_static[PP ? 16 : 2 * RING * TILE_BYTES];
+  constexpr bool QLDS = PP || QS;   // Q fragments live in LDS: ring + NW * 8 KiB exceed the static limit
+  __shared__ __attribute__((aligned(16))) unsigned char smem_static[QLDS ? 16 : 2 * RING * TILE_BYTES];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
-  unsigned char* const smem = PP ? smem_dyn : smem_static;
+  unsigned char* const smem = QLDS ? smem_dyn : smem_static;
   constexpr int Q_OFF = 2 * RING * TILE_BYTES;
 
   const int tid = threadIdx.x;
@@ -159,9 +167,11 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #pragma unroll
   for (int r = 0; r < 16; ++r) { A.o0[r] = 0.f; A.o1[r] = 0.f; Bk.o0[r] = 0.f; Bk.o1[r] = 0.f; }
   A.la = A.lb = Bk.la = Bk.lb = f32x2{0.f, 0.f};
-  A.m_run = Bk.m_run = -INFINITY;
+  A.m_run = Bk.m_run = QS ? 0.f : -INFINITY;
   A.l_done = Bk.l_done = 0.f;
-  const float c2 = p.scale_log2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { A.nm[r] = 0.f; Bk.nm[r] = 0.f; }
+  const float c2 = QS ? 1.0f : p.scale_log2;
   const float lazy_thr = 6.0f / c2;
 
   int seg_b = 0, t0_b = tile_begin;
@@ -197,7 +207,31 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
     return max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), mx);
   };
-  auto softmax_rest = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], float mx) {
+  auto softmax_rest = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], float mx, bool force) {
+    if (QS) {
+      // scores are exponents relative to the reference (it came in through the C operand): mx is the growth
+      if (force || __any(mx > lazy_thr)) {
+        const float d = force ? mx : max3(mx, 0.f, 0.f);
+        const float alpha = fast_exp2(-d);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { R.o0[r] *= alpha; R.o1[r] *= alpha; s0[r] -= d; s1[r] -= d; }
+        R.la *= alpha;
+        R.lb *= alpha;
+        if (FOLD) R.l_done *= alpha;
+        R.m_run += d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) R.nm[r] = -R.m_run;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 t0v = {fast_exp2(s0[r]), fast_exp2(s0[r + 1])};
+        f32x2 t1v = {fast_exp2(s1[r]), fast_exp2(s1[r + 1])};
+        R.la += t0v;
+        R.lb += t1v;
+        s0[r] = t0v[0]; s0[r + 1] = t0v[1];
+        s1[r] = t1v[0]; s1[r + 1] = t1v[1];
+      }
+    } else {
     if (__any(mx > R.m_run + lazy_thr)) {  // lazy max: keep the reference while P stays <= 2^6
       const float m_new = max3(R.m_run, mx, mx);
       const float alpha = fast_exp2((R.m_run - m_new) * c2);
@@ -245,15 +279,16 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       s1[r] = t1v[0]; s1[r + 1] = t1v[1];
     }
     }
+    }
     pk[0][0] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
     pk[0][1] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
     pk[1][0] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
     pk[1][1] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
   };
 
-  auto softmax = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], int valid) {
+  auto softmax = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], int valid, bool force = false) {
     const float mx = row_max(s0, s1, valid);
-    softmax_rest(R, s0, s1, pk, mx);
+    softmax_rest(R, s0, s1, pk, mx, force);
   };
 
   // FOLD: close segment `sc`; `has_next`: another (reference) segment follows in this piece
@@ -305,7 +340,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qA[ks]), "v"(qB[ks]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (PP) {
+  if (QLDS) {
     unsigned char* ql = smem + Q_OFF + wid * 8192 + lane * 16;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -317,9 +352,11 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 
   // S^T = K Q^T of one tile for both row blocks: every K fragment is fetched once, used twice
   auto qk_tile = [&](const unsigned char* Kb, f32x16& sa0, f32x16& sa1, f32x16& sb0, f32x16& sb1) {
+    if (!QS) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; }
-    if (PP) {   // Q fragments from the wave's LDS copy, one step ahead like the K fragments
+      for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; }
+    }
+    if (QLDS) {   // Q fragments from the wave's LDS copy, one step ahead like the K fragments
       const unsigned char* ql = smem + Q_OFF + wid * 8192 + lane * 16;
       v8 kc0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[0]);
       v8 kc1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[0]);
@@ -334,12 +371,30 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
           qan = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (ks + 1) * 1024);
           qbn = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + ks + 1) * 1024);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        sa0 = Tr::mfma(kc0, qa, sa0);
-        sa1 = Tr::mfma(kc1, qa, sa1);
-        sb0 = Tr::mfma(kc0, qb, sb0);
-        sb1 = Tr::mfma(kc1, qb, sb1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (QLDS) __builtin_amdgcn_sched_barrier(0);
+        if (QS && ks == 0) {
+          // minus the running reference rides in on the C operand.  Spelled in asm: through the builtin hipcc takes
+          // the tied (dst = C) form for three of the four and first copies the 16-register block into the
+          // destination - 48 moves per tile where 64 multiply-adds were saved.  Three MFMAs separate each of these
+          // from the first MFMA that accumulates onto its result (the sched_barriers keep that order).
+          if (std::is_same<T, __bf16>::value) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sa0) : "v"(kc0), "v"(qa), "v"(A.nm));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sa1) : "v"(kc1), "v"(qa), "v"(A.nm));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sb0) : "v"(kc0), "v"(qb), "v"(Bk.nm));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sb1) : "v"(kc1), "v"(qb), "v"(Bk.nm));
+          } else {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sa0) : "v"(kc0), "v"(qa), "v"(A.nm));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sa1) : "v"(kc1), "v"(qa), "v"(A.nm));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sb0) : "v"(kc0), "v"(qb), "v"(Bk.nm));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sb1) : "v"(kc1), "v"(qb), "v"(Bk.nm));
+          }
+        } else {
+          sa0 = Tr::mfma(kc0, qa, sa0);
+          sa1 = Tr::mfma(kc1, qa, sa1);
+          sb0 = Tr::mfma(kc0, qb, sb0);
+          sb1 = Tr::mfma(kc1, qb, sb1);
+        }
+        if (QLDS) __builtin_amdgcn_sched_barrier(0);
         kc0 = kn0; kc1 = kn1; qa = qan; qb = qbn;
       }
     } else {
@@ -448,8 +503,8 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 
     const int valid = c_len - ct0 * KVB;
     v8 pkA[2][2], pkB[2][2];
-    softmax(A, sa0, sa1, pkA, valid);
-    softmax(Bk, sb0, sb1, pkB, valid);
+    softmax(A, sa0, sa1, pkA, valid, QS && t == 0);
+    softmax(Bk, sb0, sb1, pkB, valid, QS && t == 0);
 
     pv_tile(smem + V_OFF + cur * TILE_BYTES, pkA, pkB);
     if (++ct0 == c_ntile) {
@@ -477,6 +532,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
       l_fin = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
+    const float m_raw = QS ? R.m_run / p.scale_log2 : R.m_run;   // the combine kernel and the LSE work in raw-score units
     if (npiece > 1) {
       const int64_t prow = ((int64_t)((xcd * (p.sk_ix - p.sk_full) + (item_local - p.sk_full)) * npiece + piece)) * QB + wid * 64 + rowoff + lq;
       float* wo = p.ws_o + prow * 64;
@@ -489,7 +545,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         *(f32x4*)(wo + 32 + 8 * g4 + 4 * hi) = x1;
       }
       if (hi == 0) {
-        p.ws_ml[prow * 2] = R.m_run;
+        p.ws_ml[prow * 2] = m_raw;
         p.ws_ml[prow * 2 + 1] = l_fin;
       }
       return;
@@ -507,7 +563,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       }
 #ifndef W64_PP_TRACE
       if (p.lse != nullptr && hi == 0)
-        p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = R.m_run * p.scale + __logf(l_fin);
+        p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_raw * p.scale + __logf(l_fin);
 #endif
     }
   };
@@ -515,7 +571,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   finish(Bk, qrowB, 32);
 }
 
-template <typename T, bool FOLD, int NW = 4, bool PP = false>
+template <typename T, bool FOLD, int NW = 4, bool PP = false, bool QS = false>
 hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   AttnKParams p = p0;
   constexpr int QB = NW * 64;
@@ -537,19 +593,19 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.ws_ml = p.ws + (size_t)8 * rem * k * QB * 64;
   const int grid = 8 * (full + rem * k);
   size_t dyn_lds = 0;
-  if (PP) {
-    dyn_lds = (size_t)2 * 4 * TILE_BYTES + (size_t)NW * 8192;   // ring of 4 K/V pairs + the waves' Q fragments
+  if (PP || QS) {
+    dyn_lds = (size_t)2 * (PP ? 4 : W64_RING) * TILE_BYTES + (size_t)NW * 8192;   // K/V ring + the waves' Q fragments
     static bool attr_set[64] = {};   // per instantiation and per device; idempotent, so a race only repeats the call
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
     if (!attr_set[dev]) {
-      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, PP>,
+      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, PP, QS>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
       if (ea != hipSuccess) return ea;
       attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, PP>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
+  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, PP, QS>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || k <= 1) return e;
   return ir_launch_shared_attn_combine(p, std::is_same<T, __bf16>::value ? 1 : 0, QB, rem, s);
@@ -570,6 +626,10 @@ hipError_t ir_launch_shared_attn_fwd_w64x8_pp(const AttnKParams& p, int dtype, h
 #endif
 
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s) {  // 8-wave (512-row) workgroups
+  if (p.q_prescaled) {   // IR_FLAG_Q_PRESCALED: the QS instantiation
+    if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8, false, true>(p, s) : launch<_Float16, true, 8, false, true>(p, s);
+    return dtype == 1 ? launch<__bf16, false, 8, false, true>(p, s) : launch<_Float16, false, 8, false, true>(p, s);
+  }
   return launch_x8<false>(p, dtype, s);
 }
 

@@ -232,11 +232,11 @@ def time_shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: i
 
 
 def shared_attention_kernel_name(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
-                                 include_self: bool = True, adain=None) -> str:
+                                 include_self: bool = True, adain=None, q_prescaled: bool = False) -> str:
     """which kernel the dispatcher launches for these tensors (reporting only)"""
     q, k_self, v_self, ref_k, ref_v = _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain)
     out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=q.dtype, device=q.device)
-    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, None, True)
+    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, None, True, q_prescaled)
     return _lib.lib().ir_shared_attn_kernel_name(C.byref(args)).decode()
 
 
@@ -369,9 +369,11 @@ def linear_supported(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
 
 
 @_on_tensor_device
-def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, scale_cols: int = 0,
+           col_scale: float = 1.0) -> torch.Tensor:
     """``F.linear(x, weight, bias)`` for 16-bit ``x (..., K)``, ``weight (N, K)`` with K <= 320 or K = 640
-    (``ir_linear_fwd``): fp32 accumulation, one rounding.  Raises for unsupported shapes."""
+    (``ir_linear_fwd``): fp32 accumulation, one rounding.  Raises for unsupported shapes.  ``scale_cols`` / ``col_scale``:
+    the first ``scale_cols`` output columns are multiplied by ``col_scale`` in fp32 before that rounding."""
     _need_gpu(x, weight, bias)
     _forward_only(x, weight, bias)
     n, k = weight.shape
@@ -379,9 +381,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
         x2 = x2.contiguous()
     y = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
-    rc = _lib.lib().ir_linear_fwd(_dtype_code(x), x2.shape[0], n, k, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
-                                  weight.stride(0), None if bias is None else bias.data_ptr(), y.data_ptr(), n, _stream())
-    _lib.check(rc, "ir_linear_fwd")
+    rc = _lib.lib().ir_linear_fwd_scaled(_dtype_code(x), x2.shape[0], n, k, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
+                                         weight.stride(0), None if bias is None else bias.data_ptr(), y.data_ptr(), n,
+                                         int(scale_cols), float(col_scale), _stream())
+    _lib.check(rc, "ir_linear_fwd_scaled")
     return y.view(*x.shape[:-1], n)
 
 

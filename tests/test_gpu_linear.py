@@ -95,3 +95,22 @@ def test_linear_stress_full_size_against_vendor_gemm():
         assert (y.float() - ref.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref.float().abs().max().item()), it
         y2, ref2 = ops.linear(x, wo6, bo6), torch.nn.functional.linear(x, wo6, bo6)
         assert (y2.float() - ref2.float()).abs().max().item() <= 2.0 ** -6 * max(1.0, ref2.float().abs().max().item()), it
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("k", [320, 640])
+def test_leading_columns_scaled_before_the_rounding(dtype, k):
+    """ir_linear_fwd_scaled: columns [0, scale_cols) carry col_scale, applied to the fp32 accumulator (one rounding):
+    equal to rounding the scaled float64 product, NOT to scaling the rounded product"""
+    from instantrestore_amd import ops
+    torch.manual_seed(4)
+    m, n, sc, cs = 1000, 3 * k, k, 0.125 * 1.4426950408889634
+    x = torch.randn(m, k).to(dtype)
+    w = (torch.randn(n, k) / k ** 0.5).to(dtype)
+    y = ops.linear(x.cuda(), w.cuda(), None, scale_cols=sc, col_scale=cs).float().cpu().double()
+    ref = x.double() @ w.double().T
+    ref[:, :sc] *= cs
+    ulp = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}[dtype]
+    assert (y - ref).abs().max().item() <= ulp * 1.05 * max(1.0, ref.abs().max().item())   # half an ulp of the largest value + accumulation
+    plain = ops.linear(x.cuda(), w.cuda(), None).float().cpu().double()
+    assert torch.equal(plain[:, sc:], y[:, sc:])                                             # the other columns are untouched

@@ -210,3 +210,98 @@ def test_bf16_error_before_and_after_the_output_rounding():
     finally:
         ops.set_attn_variant(0)
     assert torch.equal(out32.to(dt), out16_sp)
+
+
+@pytest.mark.parametrize("variant", [0, 11, 13], ids=["default", "pipe32", "w64x8qs"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(1, 1, 4096, 4, 4096, True, True), (1, 2, 1024, 2, 1024, False, False),
+                                   (2, 1, 200, 3, 72, True, True), (1, 2, 64, 0, 0, True, False)],
+                         ids=["L4096N4fold", "L1024N2", "ragged", "plain"])
+def test_prescaled_q_contract(variant, dtype, shape):
+    """IR_FLAG_Q_PRESCALED: q holds Q * scale * log2(e) (one rounding, done by the projection).  The kernels then skip
+    the per-score multiply-add: results against the float64 oracle evaluated on the value q REPRESENTS, q' / (scale *
+    log2 e), at the default tolerance; LSE in natural-log units of the reference's scores; also when the first tile's
+    maximum is far below zero (forced start) and when a later tile raises the reference (spiked key)."""
+    from instantrestore_amd import ops
+    B, H, L, N, Lr, inc, ad = shape
+    g = torch.Generator().manual_seed(77 + L)
+    C = H * 64
+    c = 0.125 * 1.4426950408889634
+    qp = (torch.randn(B, L, C, generator=g) * c - (0.9 if L == 200 else 0.0)).to(dtype)   # the pre-scaled tensor itself
+    k, v = torch.randn(B, L, C, generator=g).to(dtype), (torch.randn(B, L, C, generator=g) * 0.8 + 0.2).to(dtype)
+    rk = torch.randn(B, N, Lr, C, generator=g).to(dtype) if N else None
+    rv = (torch.randn(B, N, Lr, C, generator=g) * 1.3 - 0.4).to(dtype) if N else None
+    if N:
+        rk[:, N - 1, Lr // 2] *= 6.0          # a spiked key late in the walk: the lazy reference must move
+    f = lambda t: None if t is None else t.float().numpy().astype(np.float64)
+    rows = torch.arange(0, L, max(1, L // 256))
+    q_equiv = f(qp[:, rows]) / c
+    ref = O.shared_attention_np(q_equiv, f(k), f(v), f(rk), f(rv), H, 0.125, ad and N > 0, inc)
+    cu = lambda t: None if t is None else t.cuda()
+    ops.set_attn_variant(variant)
+    try:
+        aff = ops.adain_stats(cu(v), cu(rv), heads=H) if (ad and N) else None
+        out, lse = ops.shared_attention(cu(qp), cu(k), cu(v), cu(rk), cu(rv), heads=H, scale=0.125, include_self=inc,
+                                        adain=aff, return_lse=True, q_prescaled=True)
+    finally:
+        ops.set_attn_variant(0)
+    tol = {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    o = out[:, rows].float().cpu().numpy().astype(np.float64)
+    assert np.isfinite(o).all()
+    assert np.abs(o - ref).max() <= tol * max(1.0, np.abs(ref).max()), np.abs(o - ref).max()
+    qh = O.head_to_batch_dim_np(q_equiv, H)
+    ek, _ = O.extended_kv_np(f(k), f(v), f(rk), f(rv), H, False, inc)
+    sc = np.matmul(qh, ek.transpose(0, 2, 1)) * 0.125
+    m = sc.max(-1)
+    lse_ref = (m + np.log(np.exp(sc - m[..., None]).sum(-1))).reshape(B, H, len(rows))
+    assert np.abs(lse[:, :, rows].cpu().numpy() - lse_ref).max() <= 2e-3 * max(1.0, np.abs(lse_ref).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_processor_with_q_prescaled_in_the_projection_epilogue(dtype):
+    """At the 64x64-token layer class the fused q/k/v GEMM is this library's own kernel: its q third leaves the epilogue
+    as Q * scale * log2(e) (fp32 accumulator * factor, ONE rounding) and the attention runs its pre-scaled-Q form.  Whole
+    processor (fp32 weights + activations under autocast) against a float64 evaluation on sampled query rows."""
+    from face_replace.models.attn_processors import SharedAttnProcessor
+    from instantrestore_amd import attn_processors as ap, ops
+    from instantrestore_amd.attention import Attention
+    torch.manual_seed(21)
+    B, H, L, N = 5, 5, 4096, 2
+    C = H * 64
+    attn = Attention(query_dim=C, heads=H, dim_head=64,
+                     processor=SharedAttnProcessor(self_attn_idx=0, use_adain=True, train_input=True))
+    with torch.no_grad():
+        for lin in (attn.to_q, attn.to_k, attn.to_v, attn.to_out[0]):
+            lin.weight.copy_(torch.randn(lin.weight.shape) / C ** 0.5)
+    x = torch.randn(B, L, C)
+    rk, rv = torch.randn(B, N, L, C).to(dtype), (torch.randn(B, N, L, C) * 0.8 + 0.3).to(dtype)
+    attn = attn.cuda()
+    seen = []
+    orig = ops.shared_attention
+    def spy(*a, **kw):
+        seen.append(bool(kw.get("q_prescaled", False)))
+        return orig(*a, **kw)
+    ops.shared_attention = spy
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+            got = attn(x.cuda(), ref_keys=[rk.cuda()], ref_values=[rv.cuda()]).float().cpu()
+            ap.PRESCALE_Q = False
+            plain = attn(x.cuda(), ref_keys=[rk.cuda()], ref_values=[rv.cuda()]).float().cpu()
+    finally:
+        ops.shared_attention = orig
+        ap.PRESCALE_Q = True
+    assert seen == [True, False], seen           # the first call really took the pre-scaled path
+    rows = torch.arange(7, L, 61)
+    xd = x.to(dtype).double()                     # the 16-bit cast of the activations is part of the path
+    w = lambda m: m.weight.detach().cpu().to(dtype).double()
+    q, k, v = xd[:, rows] @ w(attn.to_q).T, xd @ w(attn.to_k).T, xd @ w(attn.to_v).T
+    r16 = lambda t: t.float().to(dtype).double()
+    k, v = r16(k), r16(v)                         # projections leave the GEMM rounded to 16 bit (q: after its factor)
+    c = 0.125 * 1.4426950408889634
+    qn = (r16(q * c) / c).numpy()
+    ref = O.shared_attention_np(qn, k.numpy(), v.numpy(), rk.double().numpy(), rv.double().numpy(), H, 0.125, True, True)
+    want = torch.from_numpy(ref) @ w(attn.to_out[0]).T + attn.to_out[0].bias.detach().cpu().double()
+    tol = {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    bound = 2 * tol * max(1.0, want.abs().max().item())
+    assert (got[:, rows].double() - want).abs().max().item() <= bound
+    assert (plain[:, rows].double() - want).abs().max().item() <= bound      # and so is the plain path (same target)

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from instantrestore_amd import ops
 
-variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "13,15").split(",")]
+variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "13,16").split(",")]
+PRESC = len(sys.argv) > 3 and sys.argv[3] == "presc"   # also run every variant with IR_FLAG_Q_PRESCALED
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 B, N, L, H = 8, 4, 4096, 5
 C = H * 64
@@ -28,10 +29,12 @@ def poll(stop, out):
             out.append(("err", str(e)[:40]))
         time.sleep(0.3)
 
-def run(var, data):
+def run(var, data, presc=False):
     ops.set_attn_variant(var)
     qq, kk, vv, rkk, rvv = data
-    kw = dict(heads=H, scale=0.125, include_self=True, adain=aff)
+    if presc:
+        qq = (qq.float() * (0.125 * 1.4426950408889634)).to(qq.dtype)
+    kw = dict(heads=H, scale=0.125, include_self=True, adain=aff, q_prescaled=presc)
     ops.shared_attention(qq, kk, vv, rkk, rvv, **kw)
     torch.cuda.synchronize()
     stop, out = threading.Event(), []
@@ -52,6 +55,7 @@ def run(var, data):
 zeros = tuple(torch.zeros_like(x) for x in (q, k, v, rk, rv))
 for var in variants:
     for name, data in (("random", (q, k, v, rk, rv)), ("zeros", zeros)):
-        ms, out = run(var, data)
-        print(f"v{var} {name}: {ms:.4f} ms/launch  samples (W, sclk MHz): {out[1:-1][:8]}")
+        for presc in ((False, True) if PRESC else (False,)):
+            ms, out = run(var, data, presc)
+            print(f"v{var} {name}{' prescaled-Q' if presc else ''}: {ms:.4f} ms/launch  samples (W, sclk MHz): {out[1:-1][:8]}")
 print(subprocess.run(["rocm-smi", "--showmaxpower", "-d", "0"], capture_output=True, text=True).stdout[-300:])

@@ -284,10 +284,12 @@ int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32
  */
 int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                   int64_t w_ld, const void* bias, void* y, int64_t y_ld, void* stream);
-/* The same with output columns [0, scale_cols) multiplied by col_scale in the fp32 accumulator, before the one rounding
+/* The same with (a) output columns [0, scale_cols) multiplied by col_scale in the fp32 accumulator, before the one rounding
  * (y = acc * col_scale + bias there): the fused q/k/v projection hands the attention kernel Q * scale * log2(e)
- * (IR_FLAG_Q_PRESCALED) at no extra rounding.  scale_cols % 32 == 0. */
-int ir_linear_fwd_scaled(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+ * (IR_FLAG_Q_PRESCALED) at no extra rounding; scale_cols % 32 == 0; (b) x_is_f32 != 0: x is fp32 (x_ld in fp32
+ * elements) and is rounded to `dtype` while it is loaded - the `.to(fp16)` the reference's autocast performs on the
+ * LayerNorm output ahead of every projection (inference/test.py:83), without its pass over memory. */
+int ir_linear_fwd_scaled(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                          int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
                          void* stream);
 

@@ -66,7 +66,7 @@ SYMBOLS = {
     "ir_preprocess_lanczos_u8": (C.c_int, [C.POINTER(ImageDesc), i32, i32, i32, vp, vp]),
     "ir_freeu_fourier_filter": (C.c_int, [i32, i64, i32, i32, vp, i64, vp, i64, i32, f32, vp]),
     "ir_linear_fwd": (C.c_int, [i32, i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp]),
-    "ir_linear_fwd_scaled": (C.c_int, [i32, i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, i32, f32, vp]),
+    "ir_linear_fwd_scaled": (C.c_int, [i32, i32, i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, i32, f32, vp]),
     "ir_zero_invalid_refs": (C.c_int, [i32, i32, i32, i32, vp, vp, i64, i64, i64, i64,
                                        vp, i64, i64, i64, i64, vp]),
 }

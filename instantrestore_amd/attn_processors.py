@@ -120,6 +120,7 @@ def _linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> t
 
 
 LOG2E = 1.4426950408889634
+FUSED_CAST = True   # own GEMM: fp32 activations (autocast) are rounded to the compute dtype while they are loaded
 PRESCALE_Q = True   # own fused q/k/v GEMM: q leaves its epilogue as Q * attn.scale * log2(e) (still one rounding)
 
 
@@ -151,9 +152,12 @@ def _project_qkv(attn, st: _Prepared):
         return tq(st.hidden), tk(src), tv(src), False
     dtype = _autocast_or(effs[0][0].weight, st.hidden)
     w = _lora.cached_weight(attn, "_ir_qkv_cache", (tq, tk, tv), dtype)
-    x = st.hidden if st.hidden.dtype == dtype else st.hidden.to(dtype)
     c = w.shape[0] // 3
-    presc = bool(PRESCALE_Q and c % 32 == 0 and _own_gemm(x, w, None))
+    x = st.hidden
+    own = _own_gemm(x, w, None)      # fp32 activations go straight in: the own GEMM casts them while loading
+    if x.dtype != dtype and not (own and FUSED_CAST):
+        x = x.to(dtype)
+    presc = bool(PRESCALE_Q and c % 32 == 0 and own)
     qkv = _ops.linear(x, w, None, scale_cols=c, col_scale=float(attn.scale) * LOG2E) if presc else _linear(x, w, None)
     return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], presc
 
@@ -170,7 +174,9 @@ def _project_kv_only(attn, st: _Prepared):
             dtype = _autocast_or(effs[0][0].weight, st.hidden)
             w = _lora.cached_weight(attn, "_ir_qkv_cache", (attn.to_q, tk, tv), dtype)
             c = w.shape[0] // 3
-            x = st.hidden if st.hidden.dtype == dtype else st.hidden.to(dtype)
+            x = st.hidden
+            if x.dtype != dtype and not (FUSED_CAST and _own_gemm(x, w[c:], None)):
+                x = x.to(dtype)
             kv = _linear(x, w[c:], None)
             return kv[..., :c], kv[..., c:]
     return tk(src), tv(src)

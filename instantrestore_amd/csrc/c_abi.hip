@@ -67,9 +67,8 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->out_f32 = (a->flags & IR_FLAG_OUT_F32) ? 1 : 0;
   if (p->out_f32 && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_SP64)
     return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_OUT_F32 is implemented by the SP64 kernel only");
-  if (p->q_prescaled && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_SP64 && a->tuning != IR_TUNE_W64X8 &&
-      a->tuning != IR_TUNE_PIPE32_PRESCALE_Q)
-    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8, PIPE32_PRESCALE_Q and SP64 kernels only");
+  if (p->q_prescaled && (p->out_f32 || (a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q)))
+    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8 and PIPE32_PRESCALE_Q kernels only (and not with IR_FLAG_OUT_F32)");
   p->tiles_self = inc ? (a->len_self + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->tiles_ref = a->n_refs > 0 ? (a->len_ref + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->ntiles = p->tiles_self + a->n_refs * p->tiles_ref;
@@ -352,10 +351,10 @@ int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32
 
 int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                   int64_t w_ld, const void* bias, void* y, int64_t y_ld, void* stream) {
-  return ir_linear_fwd_scaled(dtype, m, n, k, x, x_ld, w, w_ld, bias, y, y_ld, 0, 1.0f, stream);
+  return ir_linear_fwd_scaled(dtype, 0, m, n, k, x, x_ld, w, w_ld, bias, y, y_ld, 0, 1.0f, stream);
 }
 
-int ir_linear_fwd_scaled(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+int ir_linear_fwd_scaled(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                          int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
                          void* stream) {
   if (scale_cols < 0 || scale_cols > n || (scale_cols % 32) != 0) return fail(IR_ERR_INVALID_ARG, "scale_cols %d: a multiple of 32 in [0, N]", scale_cols);
@@ -374,7 +373,7 @@ int ir_linear_fwd_scaled(int32_t dtype, int64_t m, int32_t n, int32_t k, const v
   LinearKParams p;
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.x_ld = x_ld; p.w_ld = w_ld; p.y_ld = y_ld;
   p.M = (int32_t)m; p.N = n; p.K = k; p.nsplit = 1;
-  p.scale_cols = scale_cols; p.col_scale = col_scale;
+  p.scale_cols = scale_cols; p.col_scale = col_scale; p.x_f32 = x_is_f32 ? 1 : 0;
   const hipError_t e = ir_launch_linear_skinny(p, dtype, (hipStream_t)stream);
   if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "linear launch: %s", hipGetErrorString(e));
   return IR_OK;

@@ -152,6 +152,7 @@ struct LinearKParams {
   void* y;           // (M, N) rows y_ld elements apart
   int64_t x_ld, w_ld, y_ld;
   int32_t M, N, K, nsplit;
+  int32_t x_f32;        // x is fp32 (x_ld in fp32 elements): cast to the 16-bit type while loading the resident fragments
   int32_t scale_cols;   // output columns [0, scale_cols) are multiplied by col_scale in fp32 before the rounding
   float col_scale;      // (scale_cols % 32 == 0; 0 = none): the softmax scale * log2(e) on the q third of a fused q/k/v
 };

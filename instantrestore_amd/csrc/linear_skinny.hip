@@ -48,11 +48,29 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   v8 xA[4 * KS], xB[4 * KS];
   {
     const int ra = rowA < p.M ? rowA : p.M - 1, rb = rowB < p.M ? rowB : p.M - 1;
-    const T* base = (const T*)p.x + hi * 8;
+    if (p.x_f32) {
+      // fp32 activations (LayerNorm output under autocast, test.py:83): the cast to the 16-bit compute type happens
+      // here, on the way into the resident fragments (round to nearest even, the bytes `.to(dtype)` would produce) -
+      // instead of a separate pass that reads 4 and writes 2 bytes per element ahead of every projection
+      // one row block at a time: all 40 fp32 fragments in flight at once would need 320 registers and the allocator
+      // answers by spilling resident fragments to scratch (reloaded in the main loop, each reload draining the W stream)
+      const float* base = (const float*)p.x + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4 * KS; ++ks) {
-      xA[ks] = *(const v8*)(base + (int64_t)ra * p.x_ld + ks * 16);
-      xB[ks] = *(const v8*)(base + (int64_t)rb * p.x_ld + ks * 16);
+      for (int ks = 0; ks < 4 * KS; ++ks)
+        xA[ks] = __builtin_convertvector(*(const f32x8*)(base + (int64_t)ra * p.x_ld + ks * 16), v8);
+#pragma unroll
+      for (int ks = 0; ks < 4 * KS; ++ks) asm volatile("" : "+v"(xA[ks]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4 * KS; ++ks)
+        xB[ks] = __builtin_convertvector(*(const f32x8*)(base + (int64_t)rb * p.x_ld + ks * 16), v8);
+    } else {
+      const T* base = (const T*)p.x + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4 * KS; ++ks) {
+        xA[ks] = *(const v8*)(base + (int64_t)ra * p.x_ld + ks * 16);
+        xB[ks] = *(const v8*)(base + (int64_t)rb * p.x_ld + ks * 16);
+      }
     }
   }
 
@@ -205,11 +223,24 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
   v8 xA[4 * KSH], xB[4 * KSH];
   {
     const int ra = rowA < p.M ? rowA : p.M - 1, rb2 = rowB < p.M ? rowB : p.M - 1;
-    const T* base = (const T*)p.x + kh * (64 * KSH) + hi * 8;
+    if (p.x_f32) {   // fp32 activations: cast on the way into the resident fragments (see linear_skinny_kernel)
+      const float* base = (const float*)p.x + kh * (64 * KSH) + hi * 8;
 #pragma unroll
-    for (int ks = 0; ks < 4 * KSH; ++ks) {
-      xA[ks] = *(const v8*)(base + (int64_t)ra * p.x_ld + ks * 16);
-      xB[ks] = *(const v8*)(base + (int64_t)rb2 * p.x_ld + ks * 16);
+      for (int ks = 0; ks < 4 * KSH; ++ks)
+        xA[ks] = __builtin_convertvector(*(const f32x8*)(base + (int64_t)ra * p.x_ld + ks * 16), v8);
+#pragma unroll
+      for (int ks = 0; ks < 4 * KSH; ++ks) asm volatile("" : "+v"(xA[ks]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 4 * KSH; ++ks)
+        xB[ks] = __builtin_convertvector(*(const f32x8*)(base + (int64_t)rb2 * p.x_ld + ks * 16), v8);
+    } else {
+      const T* base = (const T*)p.x + kh * (64 * KSH) + hi * 8;
+#pragma unroll
+      for (int ks = 0; ks < 4 * KSH; ++ks) {
+        xA[ks] = *(const v8*)(base + (int64_t)ra * p.x_ld + ks * 16);
+        xB[ks] = *(const v8*)(base + (int64_t)rb2 * p.x_ld + ks * 16);
+      }
     }
   }
 

@@ -458,7 +458,6 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   if (p.out_f32) return ir_launch_shared_attn_fwd_sp(p, dtype, s);
   if (p.q_prescaled) {
     if ((base == 0 && ir_attn_default_is_w64(p)) || base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
-    if (base == 16) return ir_launch_shared_attn_fwd_sp(p, dtype, s);
     return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);   // the 32-row kernel's pre-scaled-Q form, minus its own Q rounding
   }
   switch (base) {

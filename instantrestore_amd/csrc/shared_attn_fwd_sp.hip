@@ -624,7 +624,10 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
 template <typename T>
 hipError_t launch_t(const AttnKParams& p, hipStream_t s) {
   const bool fold = p.aa != nullptr;
-  if (p.q_prescaled) return fold ? launch<T, true, true>(p, s) : launch<T, false, true>(p, s);
+  // the PRESC template path of this kernel is not instantiated: it failed the pre-scaled-Q contract test on multi-tile
+  // walks (and ran slower: two more 16-register blocks push the allocator into AGPR copies); pre-scaled Q is served by the
+  // 64-row and 32-row kernels (shared_attn_fwd.hip)
+  if (p.q_prescaled) return hipErrorInvalidValue;
   return fold ? launch<T, true, false>(p, s) : launch<T, false, false>(p, s);
 }
 

@@ -362,9 +362,9 @@ LINEAR_SPLIT_K = (640,)
 def linear_supported(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
     """shapes / layouts ``ir_linear_fwd`` implements (the caller keeps ``F.linear`` otherwise)"""
     n, k = weight.shape
-    return (x.is_cuda and x.dtype in _DT and weight.dtype == x.dtype and x.shape[-1] == k
+    return (x.is_cuda and weight.dtype in _DT and (x.dtype == weight.dtype or x.dtype == torch.float32) and x.shape[-1] == k
             and ((k % 64 == 0 and k <= LINEAR_MAX_K) or k in LINEAR_SPLIT_K) and n % 32 == 0 and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
-            and (bias is None or (bias.dtype == x.dtype and bias.is_contiguous() and n <= 4096))
+            and (bias is None or (bias.dtype == weight.dtype and bias.is_contiguous() and n <= 4096))
             and x.numel() > 0)
 
 
@@ -373,15 +373,16 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
            col_scale: float = 1.0) -> torch.Tensor:
     """``F.linear(x, weight, bias)`` for 16-bit ``x (..., K)``, ``weight (N, K)`` with K <= 320 or K = 640
     (``ir_linear_fwd``): fp32 accumulation, one rounding.  Raises for unsupported shapes.  ``scale_cols`` / ``col_scale``:
-    the first ``scale_cols`` output columns are multiplied by ``col_scale`` in fp32 before that rounding."""
+    the first ``scale_cols`` output columns are multiplied by ``col_scale`` in fp32 before that rounding.  ``x`` may be
+    fp32 (with 16-bit ``weight``): it is rounded to the weight's dtype while loaded (the autocast cast, fused)."""
     _need_gpu(x, weight, bias)
     _forward_only(x, weight, bias)
     n, k = weight.shape
     x2 = x.reshape(-1, k)
     if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
         x2 = x2.contiguous()
-    y = torch.empty((x2.shape[0], n), dtype=x.dtype, device=x.device)
-    rc = _lib.lib().ir_linear_fwd_scaled(_dtype_code(x), x2.shape[0], n, k, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
+    y = torch.empty((x2.shape[0], n), dtype=weight.dtype, device=x.device)
+    rc = _lib.lib().ir_linear_fwd_scaled(_dtype_code(weight), 1 if x.dtype == torch.float32 else 0, x2.shape[0], n, k, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
                                          weight.stride(0), None if bias is None else bias.data_ptr(), y.data_ptr(), n,
                                          int(scale_cols), float(col_scale), _stream())
     _lib.check(rc, "ir_linear_fwd_scaled")

@@ -114,3 +114,20 @@ def test_leading_columns_scaled_before_the_rounding(dtype, k):
     assert (y - ref).abs().max().item() <= ulp * 1.05 * max(1.0, ref.abs().max().item())   # half an ulp of the largest value + accumulation
     plain = ops.linear(x.cuda(), w.cuda(), None).float().cpu().double()
     assert torch.equal(plain[:, sc:], y[:, sc:])                                             # the other columns are untouched
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("shape", [(20000, 960, 320), (3000, 192, 128), (9000, 1920, 640), (777, 640, 640)])
+def test_fp32_activations_are_cast_while_loaded(dtype, shape):
+    """x in fp32 (LayerNorm output under autocast): ir_linear_fwd_scaled(x_is_f32) must give the bytes of
+    linear(x.to(dtype)) through the same kernel - the fused cast is the same round-to-nearest-even"""
+    from instantrestore_amd import ops
+    m, n, k = shape
+    torch.manual_seed(m)
+    x = (torch.randn(m, k) * 3.0).cuda()
+    x[0, :8] = torch.tensor([1.0 + 2 ** -9, 1.0 + 2 ** -8, -1.0 - 3 * 2 ** -10, 65504.0, 1e-8, -0.0, 3.3e4, 2 ** -15]).cuda()
+    w = (torch.randn(n, k) / k ** 0.5).to(dtype).cuda()
+    bias = torch.randn(n).to(dtype).cuda() if n <= 640 else None
+    a = ops.linear(x, w, bias)
+    b = ops.linear(x.to(dtype), w, bias)
+    assert a.dtype == dtype and torch.equal(a, b)

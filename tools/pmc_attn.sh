@@ -1,8 +1,8 @@
 #!/usr/bin/env bash
 # PMC passes over the fused attention kernel (run on the GPU box via gpurun).
-# usage: tools/pmc_attn.sh <tag> [variant] ; writes gpurun_out/pmc_<tag>/passN_counter_collection.csv
+# usage: tools/pmc_attn.sh <tag> [variant] [presc] ; writes gpurun_out/pmc_<tag>/passN_counter_collection.csv
 set -u
-TAG=${1:-x}; VAR=${2:-0}
+TAG=${1:-x}; VAR=${2:-0}; PRESC=${3:-0}
 R=$PWD; OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS"
@@ -12,7 +12,7 @@ P4="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT -o pass$i -- python $R/tools/prof_attn.py $VAR 3 > $OUT/pass$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT -o pass$i -- python $R/tools/prof_attn.py $VAR 3 4096 5 1 1 $PRESC > $OUT/pass$i.log 2>&1
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections

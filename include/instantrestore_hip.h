@@ -121,6 +121,7 @@ typedef struct ir_shared_attn_args {
 #define IR_TUNE_W64X8 13
 #define IR_TUNE_PIPE32_EARLYQK 14
 #define IR_TUNE_SP64 16
+#define IR_TUNE_TP32 17
 
 /*
  * Scratch for the remainder split: when the number of (batch, head, query-block) work items is not

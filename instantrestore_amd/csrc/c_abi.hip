@@ -67,7 +67,7 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->out_f32 = (a->flags & IR_FLAG_OUT_F32) ? 1 : 0;
   if (p->out_f32 && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_SP64)
     return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_OUT_F32 is implemented by the SP64 kernel only");
-  if (p->q_prescaled && (p->out_f32 || (a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q)))
+  if (p->q_prescaled && (p->out_f32 || (a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q && a->tuning != IR_TUNE_TP32)))
     return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8 and PIPE32_PRESCALE_Q kernels only (and not with IR_FLAG_OUT_F32)");
   p->tiles_self = inc ? (a->len_self + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->tiles_ref = a->n_refs > 0 ? (a->len_ref + IR_KV_TILE - 1) / IR_KV_TILE : 0;
@@ -108,6 +108,7 @@ const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
     case 13: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>";
     case 11: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q>";
     case 16: return "shared_attn_fwd_sp_kernel<64 rows/wave, one wave per SIMD, software-pipelined>";
+    case 17: return "shared_attn_fwd_tp_kernel<32 rows/wave, 8 waves, three-stage pipeline, MFMA/VALU interleave>";
     case 10: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max>";
     case 8: return "shared_attn_fwd_pp_kernel";
     default: return "shared_attn_fwd (tuning variant)";

@@ -91,6 +91,7 @@ hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStr
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64x8_pp(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_sp(const AttnKParams& p, int dtype, hipStream_t s);
+hipError_t ir_launch_shared_attn_fwd_tp(const AttnKParams& p, int dtype, hipStream_t s);
 bool ir_attn_default_is_w64(const AttnKParams& p);
 bool ir_attn_variant_available(int variant);
 

@@ -408,6 +408,8 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 
 // variant & 15 selects the kernel (per-call tuning field of ir_shared_attn_args; 0 = default dispatch, see
 // ir_attn_default_kernel).  Product library:
+//   17 (IR_TUNE_TP32) 32 rows per wave, two waves per SIMD, three-stage pipeline with a spelled-out interleave
+//      (shared_attn_fwd_tp.hip)
 //   16 (IR_TUNE_SP) one wave per SIMD, 64 query rows per wave, software-pipelined (shared_attn_fwd_sp.hip)
 //   13 64 query rows per wave, 8-wave (512-row) workgroups (shared_attn_fwd_w64.hip)     12 the same, 4 waves
 //   10 software-pipelined 32-row kernel, 4 waves, asm-issued LDS-DMA staging, lazy max (shared_attn_fwd_pipe.hip)
@@ -421,10 +423,10 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 bool ir_attn_variant_available(int variant) {
   const int base = variant & 31;
 #ifdef IR_ABLATIONS
-  return base <= 16;
+  return base <= 17;
 #else
   if ((variant >> 5) != 0) return false;
-  return base == 0 || base == 7 || (base >= 10 && base <= 14) || base == 16;
+  return base == 0 || base == 7 || (base >= 10 && base <= 14) || base == 16 || base == 17;
 #endif
 }
 
@@ -456,6 +458,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   // fp32 output: the one-wave-per-SIMD kernel only; pre-scaled Q: the 64-row kernel's QS instantiation where the default
   // rule (or IR_TUNE_W64X8) takes that kernel, the 32-row kernel's reference-through-C form for every other shape
   if (p.out_f32) return ir_launch_shared_attn_fwd_sp(p, dtype, s);
+  if (base == 17 && !p.out_f32) return ir_launch_shared_attn_fwd_tp(p, dtype, s);
   if (p.q_prescaled) {
     if ((base == 0 && ir_attn_default_is_w64(p)) || base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
     return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);   // the 32-row kernel's pre-scaled-Q form, minus its own Q rounding

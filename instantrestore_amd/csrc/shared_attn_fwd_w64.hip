@@ -271,8 +271,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       f32x2 t1v = {s1[r], s1[r + 1]};
       t0v = __builtin_elementwise_fma(t0v, cc, nm);
       t1v = __builtin_elementwise_fma(t1v, cc, nm);
+#ifndef W64_ABL_NOEXP   // timing ablation only (WRONG results): what do the 64 v_exp_f32 per wave and tile cost?
       t0v[0] = fast_exp2(t0v[0]); t0v[1] = fast_exp2(t0v[1]);
       t1v[0] = fast_exp2(t1v[0]); t1v[1] = fast_exp2(t1v[1]);
+#endif
       R.la += t0v;
       R.lb += t1v;
       s0[r] = t0v[0]; s0[r + 1] = t0v[1];

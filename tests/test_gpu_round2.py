@@ -212,7 +212,7 @@ def test_bf16_error_before_and_after_the_output_rounding():
     assert torch.equal(out32.to(dt), out16_sp)
 
 
-@pytest.mark.parametrize("variant", [0, 11, 13], ids=["default", "pipe32", "w64x8qs"])
+@pytest.mark.parametrize("variant", [0, 11, 13, 17], ids=["default", "pipe32", "w64x8qs", "tp32"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(1, 1, 4096, 4, 4096, True, True), (1, 2, 1024, 2, 1024, False, False),
                                    (2, 1, 200, 3, 72, True, True), (1, 2, 64, 0, 0, True, False)],

@@ -273,7 +273,9 @@ def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=28.0, reps=3):
 # ---------------------------------------------------------------------------------------------------------------------
 # labelled extras next to the headline (never `value`)
 # ---------------------------------------------------------------------------------------------------------------------
-def _time_steps(fn, steps):
+def _time_steps(fn, steps, warm=3):
+    for _ in range(warm):   # the GPU sat idle during the CPU baseline: bring clocks and caches back before timing
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):

@@ -253,3 +253,54 @@ def test_reference_unet_early_exit_harvests_identical_kv(shim):
     procs = [p for p in unet.attn_processors.values() if type(p) in [AttnProcessor]]
     assert all(p.keys is None and p.stop_after_capture is None for p in procs)   # reset and disarmed
     assert len(procs[-1].state_dict()) == 0
+
+
+def test_lora_cache_invalidation_api_and_load_state_dict_hook():
+    """writes through .data do not bump _version - explicit invalidation and a load_state_dict post hook
+    (installed by the registration functions) drop the folded weights; CPU-only logic test on the cache itself"""
+    import torch
+    from torch import nn
+    from instantrestore_amd import lora_fold
+
+    class Holder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = nn.Linear(8, 8, bias=False), nn.Linear(8, 8, bias=False)
+
+    h = Holder()
+    w1 = lora_fold.cached_weight(h, "_ir_qkv_cache", (h.a, h.b), torch.float32)
+    assert w1.shape == (16, 8) and lora_fold.cached_weight(h, "_ir_qkv_cache", (h.a, h.b), torch.float32) is w1
+    with torch.no_grad():
+        h.a.weight.data.mul_(2.0)                          # invisible to the (data_ptr, _version) key
+    assert lora_fold.cached_weight(h, "_ir_qkv_cache", (h.a, h.b), torch.float32) is w1
+    lora_fold.invalidate(h)
+    w2 = lora_fold.cached_weight(h, "_ir_qkv_cache", (h.a, h.b), torch.float32)
+    assert w2 is not w1 and torch.equal(w2[:8], h.a.weight)
+    with torch.no_grad():
+        h.b.weight.mul_(3.0)                               # a normal in-place op bumps _version: refolded on its own
+    assert torch.equal(lora_fold.cached_weight(h, "_ir_qkv_cache", (h.a, h.b), torch.float32)[8:], h.b.weight)
+    outer = nn.Sequential(h)
+    lora_fold.install_invalidation_hook(outer)
+    lora_fold.install_invalidation_hook(outer)             # idempotent
+    assert "_ir_qkv_cache" in h.__dict__
+    outer.load_state_dict(outer.state_dict())
+    assert "_ir_qkv_cache" not in h.__dict__
+    assert lora_fold.invalidate_all(outer) == 0
+
+
+def test_kv_cache_entries_are_compact_copies():
+    """a cache entry must not be a view into the harvest's fused projection buffer"""
+    import torch
+    from instantrestore_amd.kv_cache import ReferenceKVCache
+    fused = torch.randn(2 * 3, 10, 3 * 64)                              # (B*N, L, 3C) like the capture layer's q/k/v GEMM output
+    k = fused[..., 64:128].reshape(2, 3, 10, 64)[:1]                     # strided view of identity 0
+    v = fused[..., 128:].reshape(2, 3, 10, 64)[:1]
+    cache = ReferenceKVCache(max_identities=2)
+    ks, vs = cache.get_or_compute("a", lambda: ([k], [v]))
+    assert ks[0].is_contiguous() and ks[0].untyped_storage().nbytes() == ks[0].numel() * 4
+    assert torch.equal(ks[0], k) and torch.equal(vs[0], v)
+    fused.zero_()                                                         # the producer's buffer is reused: the entry must not change
+    assert float(ks[0].abs().max()) > 0
+    assert cache.nbytes("a") == 2 * 3 * 10 * 64 * 4
+    cache.get_or_compute("b", lambda: ([k], [v])); cache.get_or_compute("c", lambda: ([k], [v]))
+    assert "a" not in cache and len(cache) == 2                           # LRU eviction

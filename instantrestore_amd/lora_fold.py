@@ -142,5 +142,7 @@ def invalidate_all(module: nn.Module) -> int:
 def install_invalidation_hook(module: nn.Module) -> None:
     """``load_state_dict`` on ``module`` (checkpoint load, test.py:47-50) drops every cached folded weight below it"""
     if getattr(module, "_ir_invalidation_hook", None) is None and hasattr(module, "register_load_state_dict_post_hook"):
-        module._ir_invalidation_hook = module.register_load_state_dict_post_hook(
-            lambda mod, incompatible_keys: invalidate_all(mod))
+        def _hook(mod, incompatible_keys):   # a post hook must return None (torch asserts it)
+            invalidate_all(mod)
+
+        module._ir_invalidation_hook = module.register_load_state_dict_post_hook(_hook)

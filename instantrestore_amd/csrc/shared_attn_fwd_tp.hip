@@ -30,7 +30,7 @@ namespace {
 constexpr int KVB = IR_KV_TILE;
 constexpr int TILE_BYTES = KVB * 64 * 2;  // 8 KiB
 // TP_ABL: timing ablations (development only, WRONG results): 1 no barrier, 2 no DMA, 4 no LDS fragment reads,
-// 16 no vector work, 32 no MFMAs
+// 8 no boundary work, 16 no vector work, 32 no MFMAs
 #ifndef TP_ABL
 #define TP_ABL 0
 #endif
@@ -430,6 +430,7 @@ __global__ void __launch_bounds__(512, 1) shared_attn_fwd_tp_kernel(const AttnKP
       vf0 = vn0; vf1 = vn1;
     }
     // ---- iteration boundary: P V of tile i-1 is in O; tile i is exponentiated and summed; tile i+1 has its row max ----
+    if (!(TP_ABL & 8)) {
     asm volatile("s_nop 7\n\ts_nop 4" : "+v"(o0), "+v"(o1));   // last P V MFMAs -> VALU on O below (rare paths)
     apply_alpha();                                           // the reference change decided one iteration ago
     if (FOLD) {
@@ -445,6 +446,7 @@ __global__ void __launch_bounds__(512, 1) shared_attn_fwd_tp_kernel(const AttnKP
       const float mx = cross_max(max3(mxa, mxb, mxb));   // the two chains covered all 32 registers in clusters 10-13
       decide(mx, s0n, s1n, false);
     }
+    }   // TP_ABL & 8
     cseg = nseg_i; ct0 = nt0_i;
     if (!(TP_ABL & 1)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this iteration's two transfers were issued at its start

@@ -13,7 +13,7 @@ torch.manual_seed(0)
 dt = torch.bfloat16
 q, k, v = (torch.randn(B, L, C, device="cuda").to(dt) for _ in range(3))
 rk = torch.randn(B, N, L, C, device="cuda").to(dt); rv = torch.randn(B, N, L, C, device="cuda").to(dt)
-variants = [2] + [2 | (a << 4) for a in range(1, 8)]
+variants = [2] + [2 | (a << 5) for a in range(1, 8)]   # tuning value: kernel in bits 0-4, ablation bits above
 if len(sys.argv) > 1: variants = [int(x, 0) for x in sys.argv[1].split(",")]
 res = {v_: [] for v_ in variants}
 kw = dict(heads=H, scale=0.125, include_self=True)
@@ -24,5 +24,5 @@ for rnd in range(5):
 fl = attn_flops(B, L, 5 * L, C)
 for var in variants:
     ms = res[var]
-    print(f"variant 0x{var:02x} abl={var>>4}: min {min(ms):.4f} ms  med {statistics.median(ms):.4f} ms  -> {fl/min(ms)/1e9:7.1f} TF/s(min)")
+    print(f"variant 0x{var:02x} abl={var>>5}: min {min(ms):.4f} ms  med {statistics.median(ms):.4f} ms  -> {fl/min(ms)/1e9:7.1f} TF/s(min)")
 ops.set_attn_variant(0)

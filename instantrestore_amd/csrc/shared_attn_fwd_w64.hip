@@ -90,6 +90,9 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   const int bh = lin / p.nqb, qb = lin - bh * p.nqb;
   const int b = bh / p.H, h = bh - b * p.H;
 
+#ifdef W64_TRACE
+  const unsigned long long tr_c0 = __builtin_readcyclecounter(), tr_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- Q fragments of both row blocks -----------------------------------------------------------
   const int qrowA = qb * QB + wid * 64 + lq, qrowB = qrowA + 32;
   v8 qA[4], qB[4];
@@ -189,11 +192,15 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   // first), then rescale check, exponentials, row sums and the 16-bit probabilities
   auto row_max = [&](f32x16& s0, f32x16& s1, int valid) -> float {
     if (valid < KVB) {
+      // the compares must stay behind the branch (speculated above it they cost 30 instructions on every tile): the
+      // bound goes through a volatile statement, which is not speculated
+      int vb = valid;
+      asm volatile("" : "+s"(vb));
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (key >= valid) s0[r] = -INFINITY;
-        if (key + 32 >= valid) s1[r] = -INFINITY;
+        if (key >= vb) s0[r] = -INFINITY;
+        if (key + 32 >= vb) s1[r] = -INFINITY;
       }
     }
     float mxa = max3(s0[0], s0[1], s0[2]);
@@ -222,6 +229,17 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #pragma unroll
         for (int r = 0; r < 16; ++r) R.nm[r] = -R.m_run;
       }
+#ifdef W64_SCALAR_SUM
+      float la0 = R.la[0], la1 = R.la[1], lb0 = R.lb[0], lb1 = R.lb[1];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        s0[r] = fast_exp2(s0[r]); s0[r + 1] = fast_exp2(s0[r + 1]);
+        s1[r] = fast_exp2(s1[r]); s1[r + 1] = fast_exp2(s1[r + 1]);
+        la0 += s0[r]; la1 += s0[r + 1]; lb0 += s1[r]; lb1 += s1[r + 1];
+      }
+      R.la = f32x2{la0, la1};
+      R.lb = f32x2{lb0, lb1};
+#else
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         f32x2 t0v = {fast_exp2(s0[r]), fast_exp2(s0[r + 1])};
@@ -231,6 +249,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         s0[r] = t0v[0]; s0[r + 1] = t0v[1];
         s1[r] = t1v[0]; s1[r + 1] = t1v[1];
       }
+#endif
     } else {
     if (__any(mx > R.m_run + lazy_thr)) {  // lazy max: keep the reference while P stays <= 2^6
       const float m_new = max3(R.m_run, mx, mx);
@@ -289,7 +308,11 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   };
 
   auto softmax = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], int valid, bool force = false) {
+#ifdef W64_ABL_NOMAX   // timing ablation (right only while no later tile moves the reference): no row max after the first tile
+    const float mx = force ? row_max(s0, s1, valid) : 0.f;
+#else
     const float mx = row_max(s0, s1, valid);
+#endif
     softmax_rest(R, s0, s1, pk, mx, force);
   };
 
@@ -358,6 +381,49 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; }
     }
+#ifdef W64_QK_PF2
+    if (QLDS && QS) {   // fragments TWO contraction steps ahead: one step (4 MFMAs = 128 cycles) does not cover the LDS latency
+      const unsigned char* ql = smem + Q_OFF + wid * 8192 + lane * 16;
+      v8 kf[3][2], qf[3][2];
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        kf[st][0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[st]);
+        kf[st][1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[st]);
+        qf[st][0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + st * 1024);
+        qf[st][1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + st) * 1024);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int c = ks % 3, n2 = (ks + 2) % 3;
+        if (ks < 2) {
+          kf[n2][0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks + 2]);
+          kf[n2][1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks + 2]);
+          qf[n2][0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (ks + 2) * 1024);
+          qf[n2][1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + ks + 2) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks == 0) {
+          if (std::is_same<T, __bf16>::value) {
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sa0) : "v"(kf[c][0]), "v"(qf[c][0]), "v"(A.nm));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sa1) : "v"(kf[c][1]), "v"(qf[c][0]), "v"(A.nm));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sb0) : "v"(kf[c][0]), "v"(qf[c][1]), "v"(Bk.nm));
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sb1) : "v"(kf[c][1]), "v"(qf[c][1]), "v"(Bk.nm));
+          } else {
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sa0) : "v"(kf[c][0]), "v"(qf[c][0]), "v"(A.nm));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sa1) : "v"(kf[c][1]), "v"(qf[c][0]), "v"(A.nm));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sb0) : "v"(kf[c][0]), "v"(qf[c][1]), "v"(Bk.nm));
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sb1) : "v"(kf[c][1]), "v"(qf[c][1]), "v"(Bk.nm));
+          }
+        } else {
+          sa0 = Tr::mfma(kf[c][0], qf[c][0], sa0);
+          sa1 = Tr::mfma(kf[c][1], qf[c][0], sa1);
+          sb0 = Tr::mfma(kf[c][0], qf[c][1], sb0);
+          sb1 = Tr::mfma(kf[c][1], qf[c][1], sb1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else
+#endif
     if (QLDS) {   // Q fragments from the wave's LDS copy, one step ahead like the K fragments
       const unsigned char* ql = smem + Q_OFF + wid * 8192 + lane * 16;
       v8 kc0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[0]);
@@ -494,21 +560,118 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     close_tile(false);
     if (grp == 0) __builtin_amdgcn_s_barrier();
   } else {
+#ifdef W64_TRACE
+  // development aid: every wave of workgroup 0 stamps s_memtime at the phase boundaries of tiles 8..23 into LDS
+  // (behind the ring and the Q copies; the launcher adds 4 KiB), dumped into the head of the LSE buffer at the end
+#define TR_STAMP(ev) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && t >= 8 && t < 24 && lane == 0) \
+    *(IR_LDS unsigned*)(IR_LDS unsigned char*)(smem + Q_OFF + NW * 8192 + ((wid * 16 + (t - 8)) * 8 + (ev)) * 4) = (unsigned)__builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TR_STAMP(ev) do { } while (0)
+#endif
   int cur = 0;
+#if defined(W64_YPRIO) && W64_YPRIO == 1
+  if (NW == 8 && wid >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every age arbitration
+#endif
   for (int t = 0; t < NTILES; ++t) {
+    TR_STAMP(0);
     // pair t+RING-1 goes into the slot that was last read in step t-1
+#ifndef W64_ISSUE_AFTER_QK
     if (t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
+#endif
+    TR_STAMP(1);
 
     const unsigned char* Kb = smem + K_OFF + cur * TILE_BYTES;
     f32x16 sa0, sa1, sb0, sb1;
     qk_tile(Kb, sa0, sa1, sb0, sb1);
+#ifdef W64_ISSUE_AFTER_QK
+    // behind the QK^T MFMAs: the issue cost of the two transfers (and the segment bookkeeping) falls into the drain
+    // of the matrix pipe instead of the empty stretch after the barrier, where both waves of the SIMD paid it at once
+    if (t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    TR_STAMP(2);
+#if defined(W64_YPRIO) && W64_YPRIO == 2
+    if (NW == 8 && wid >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
     const int valid = c_len - ct0 * KVB;
     v8 pkA[2][2], pkB[2][2];
+#ifndef W64_QS_EXACTMAX
+    if (QS) {
+      // Reference checked AFTER the exponentials: the scores are exponents relative to the running reference
+      // already, so P = exp2(S) needs no row max; what has to be caught is a tile that outgrows the reference, and the
+      // tile's own row sums (needed anyway) show that: a lane's 32 probabilities sum to more than 2^11 only if one
+      // of them exceeds 2^6 - the lazy rule's bound - and to inf/NaN if one overflowed.  Then (rare; always on the
+      // first tile, whose reference is still 0) the scores are formed again - the K tile is still in LDS - and the
+      // exact path runs: row max, reference moved, accumulators and sums rescaled.  Saves the 38 v_max3 of every tile.
+      auto mask = [&](f32x16& s0, f32x16& s1) {
+        int vb = valid;
+        asm volatile("" : "+s"(vb));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= vb) s0[r] = -INFINITY;
+          if (key + 32 >= vb) s1[r] = -INFINITY;
+        }
+      };
+      auto exp_sum = [&](f32x16& s0, f32x16& s1, float (&ts)[4]) {
+        s0[0] = fast_exp2(s0[0]); s0[1] = fast_exp2(s0[1]); s1[0] = fast_exp2(s1[0]); s1[1] = fast_exp2(s1[1]);
+        ts[0] = s0[0]; ts[1] = s0[1]; ts[2] = s1[0]; ts[3] = s1[1];
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) {
+          s0[r] = fast_exp2(s0[r]); s0[r + 1] = fast_exp2(s0[r + 1]);
+          s1[r] = fast_exp2(s1[r]); s1[r + 1] = fast_exp2(s1[r + 1]);
+          ts[0] += s0[r]; ts[1] += s0[r + 1]; ts[2] += s1[r]; ts[3] += s1[r + 1];
+        }
+      };
+      auto redo = [&](RowBlock& R, f32x16& s0, f32x16& s1, float (&ts)[4]) {
+        const float mx = row_max(s0, s1, KVB);   // (masked above)
+        const float d = (t == 0) ? mx : max3(mx, 0.f, 0.f);
+        const float alpha = fast_exp2(-d);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { R.o0[r] *= alpha; R.o1[r] *= alpha; s0[r] -= d; s1[r] -= d; }
+        R.la *= alpha;
+        R.lb *= alpha;
+        if (FOLD) R.l_done *= alpha;
+        R.m_run += d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) R.nm[r] = -R.m_run;
+        exp_sum(s0, s1, ts);
+      };
+      if (valid < KVB) { mask(sa0, sa1); mask(sb0, sb1); }
+      float tsA[4], tsB[4];
+      exp_sum(sa0, sa1, tsA);
+      exp_sum(sb0, sb1, tsB);
+      const float big = max3(max3(tsA[0], tsA[1], tsA[2]), max3(tsB[0], tsB[1], tsB[2]), max3(tsA[3], tsB[3], tsB[3]));
+      if (t == 0 || __any(!(big <= 2048.f))) {
+        qk_tile(Kb, sa0, sa1, sb0, sb1);
+        if (valid < KVB) { mask(sa0, sa1); mask(sb0, sb1); }
+        redo(A, sa0, sa1, tsA);
+        redo(Bk, sb0, sb1, tsB);
+      }
+      A.la[0] += tsA[0]; A.la[1] += tsA[1]; A.lb[0] += tsA[2]; A.lb[1] += tsA[3];
+      Bk.la[0] += tsB[0]; Bk.la[1] += tsB[1]; Bk.lb[0] += tsB[2]; Bk.lb[1] += tsB[3];
+      pkA[0][0] = __builtin_convertvector(__builtin_shufflevector(sa0, sa0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+      pkA[0][1] = __builtin_convertvector(__builtin_shufflevector(sa0, sa0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+      pkA[1][0] = __builtin_convertvector(__builtin_shufflevector(sa1, sa1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+      pkA[1][1] = __builtin_convertvector(__builtin_shufflevector(sa1, sa1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+      pkB[0][0] = __builtin_convertvector(__builtin_shufflevector(sb0, sb0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+      pkB[0][1] = __builtin_convertvector(__builtin_shufflevector(sb0, sb0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+      pkB[1][0] = __builtin_convertvector(__builtin_shufflevector(sb1, sb1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+      pkB[1][1] = __builtin_convertvector(__builtin_shufflevector(sb1, sb1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+    } else
+#endif
+    {
     softmax(A, sa0, sa1, pkA, valid, QS && t == 0);
     softmax(Bk, sb0, sb1, pkB, valid, QS && t == 0);
+    }
 
     pv_tile(smem + V_OFF + cur * TILE_BYTES, pkA, pkB);
+#if defined(W64_YPRIO) && W64_YPRIO == 2
+    if (NW == 8 && wid >= 4) __builtin_amdgcn_s_setprio(0);
+#endif
+    TR_STAMP(3);
     if (++ct0 == c_ntile) {
       if (FOLD) fold_boundary(cseg, t + 1 < NTILES);
       ct0 = 0; ++cseg; c_ntile = p.tiles_ref; c_len = p.Lr;
@@ -518,9 +681,22 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     // (vector memory operations retire in issue order and nothing else was issued after them)
     if (RING == 3 && t + 2 < NTILES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_STAMP(4);
     __syncthreads();
     cur = (RING == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
   }
+#ifdef W64_TRACE
+  if (QLDS && blockIdx.x == 0 && p.lse != nullptr) {
+    __syncthreads();
+    for (int i = tid; i < NW * 16 * 8; i += NT)
+      p.lse[i] = __uint_as_float(*(IR_LDS unsigned*)(IR_LDS unsigned char*)(smem + Q_OFF + NW * 8192 + i * 4));
+    if (tid == 0) {   // shader cycles and 100 MHz ticks of this workgroup's main loop: the clock it ran at
+      p.lse[1024] = __uint_as_float((unsigned)(__builtin_readcyclecounter() - tr_c0));
+      p.lse[1025] = __uint_as_float((unsigned)(__builtin_amdgcn_s_memrealtime() - tr_r0));
+      p.lse[1026] = __uint_as_float((unsigned)NTILES);
+    }
+  }
+#endif
   }
 
   // ---- epilogue (per row block) ---------------------------------------------------------------------
@@ -563,7 +739,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
         *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
       }
-#ifndef W64_PP_TRACE
+#if !defined(W64_PP_TRACE) && !defined(W64_TRACE)
       if (p.lse != nullptr && hi == 0)
         p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_raw * p.scale + __logf(l_fin);
 #endif
@@ -597,6 +773,12 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   size_t dyn_lds = 0;
   if (PP || QS) {
     dyn_lds = (size_t)2 * (PP ? 4 : W64_RING) * TILE_BYTES + (size_t)NW * 8192;   // K/V ring + the waves' Q fragments
+#ifdef W64_TRACE
+    dyn_lds += 4096;
+#endif
+#ifdef W64_SOLO   // development aid: one 4-wave workgroup per CU = one wave per SIMD
+    dyn_lds += 48 * 1024;
+#endif
     static bool attr_set[64] = {};   // per instantiation and per device; idempotent, so a race only repeats the call
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
@@ -628,6 +810,9 @@ hipError_t ir_launch_shared_attn_fwd_w64x8_pp(const AttnKParams& p, int dtype, h
 #endif
 
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s) {  // 8-wave (512-row) workgroups
+#ifdef W64_SOLO
+  if (p.q_prescaled) return dtype == 1 ? launch<__bf16, false, 4, false, true>(p, s) : launch<_Float16, false, 4, false, true>(p, s);
+#endif
   if (p.q_prescaled) {   // IR_FLAG_Q_PRESCALED: the QS instantiation
     if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8, false, true>(p, s) : launch<_Float16, true, 8, false, true>(p, s);
     return dtype == 1 ? launch<__bf16, false, 8, false, true>(p, s) : launch<_Float16, false, 8, false, true>(p, s);

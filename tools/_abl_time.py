@@ -8,8 +8,10 @@ torch.manual_seed(0)
 q, k, v = (torch.randn(B, L, C, device="cuda").to(torch.bfloat16) for _ in range(3))
 rk = torch.randn(B, N, L, C, device="cuda").to(torch.bfloat16); rv = torch.randn(B, N, L, C, device="cuda").to(torch.bfloat16)
 ops.set_attn_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 16)
-kw = dict(heads=H, scale=0.125, include_self=True, q_prescaled=(len(sys.argv) > 2))
-if len(sys.argv) > 2: q = (q.float() * 0.125 * 1.4426950408889634).to(torch.bfloat16)
+presc = len(sys.argv) > 2 and sys.argv[2] == "presc"
+kw = dict(heads=H, scale=0.125, include_self=True, q_prescaled=presc)
+if "adain" in sys.argv: kw["adain"] = ops.adain_stats(v, rv, heads=H)
+if presc: q = (q.float() * 0.125 * 1.4426950408889634).to(torch.bfloat16)
 ops.time_shared_attention(q, k, v, rk, rv, iters=3, **kw)
 ms = min(ops.time_shared_attention(q, k, v, rk, rv, iters=10, **kw) for _ in range(3))
-print(f"{os.environ.get('IR_LIB_PATH','default')[-16:]}: {ms:.4f} ms {attn_flops(B, L, 5 * L, C) / ms / 1e9:.0f} TF/s")
+print(f"{os.environ.get('IR_LIB_PATH','default')[-24:]} {' '.join(sys.argv[1:])}: {ms:.4f} ms {attn_flops(B, L, 5 * L, C) / ms / 1e9:.0f} TF/s")

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(512, 1) shared_attn_fwd_tp_kernel(const AttnKP
     if (PRESC) {
       if (force || __any(mx > lazy_thr)) {
         const float d = force ? mx : max3(mx, 0.f, 0.f);
-        const float alpha = fast_exp2(-d);
+        const float alpha = force ? 1.f : fast_exp2(-d);   // first tile: nothing accumulated yet, and 2^-d may be inf
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] -= d; s1[r] -= d; }
         l0 *= alpha; l1 *= alpha;

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       // scores are exponents relative to the reference (it came in through the C operand): mx is the growth
       if (force || __any(mx > lazy_thr)) {
         const float d = force ? mx : max3(mx, 0.f, 0.f);
-        const float alpha = fast_exp2(-d);
+        const float alpha = force ? 1.f : fast_exp2(-d);   // first tile: nothing accumulated yet, and 2^-d may be inf
 #pragma unroll
         for (int r = 0; r < 16; ++r) { R.o0[r] *= alpha; R.o1[r] *= alpha; s0[r] -= d; s1[r] -= d; }
         R.la *= alpha;
@@ -229,17 +229,6 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #pragma unroll
         for (int r = 0; r < 16; ++r) R.nm[r] = -R.m_run;
       }
-#ifdef W64_SCALAR_SUM
-      float la0 = R.la[0], la1 = R.la[1], lb0 = R.lb[0], lb1 = R.lb[1];
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        s0[r] = fast_exp2(s0[r]); s0[r + 1] = fast_exp2(s0[r + 1]);
-        s1[r] = fast_exp2(s1[r]); s1[r + 1] = fast_exp2(s1[r + 1]);
-        la0 += s0[r]; la1 += s0[r + 1]; lb0 += s1[r]; lb1 += s1[r + 1];
-      }
-      R.la = f32x2{la0, la1};
-      R.lb = f32x2{lb0, lb1};
-#else
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         f32x2 t0v = {fast_exp2(s0[r]), fast_exp2(s0[r + 1])};
@@ -249,7 +238,6 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         s0[r] = t0v[0]; s0[r + 1] = t0v[1];
         s1[r] = t1v[0]; s1[r + 1] = t1v[1];
       }
-#endif
     } else {
     if (__any(mx > R.m_run + lazy_thr)) {  // lazy max: keep the reference while P stays <= 2^6
       const float m_new = max3(R.m_run, mx, mx);
@@ -381,49 +369,6 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; }
     }
-#ifdef W64_QK_PF2
-    if (QLDS && QS) {   // fragments TWO contraction steps ahead: one step (4 MFMAs = 128 cycles) does not cover the LDS latency
-      const unsigned char* ql = smem + Q_OFF + wid * 8192 + lane * 16;
-      v8 kf[3][2], qf[3][2];
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        kf[st][0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[st]);
-        kf[st][1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[st]);
-        qf[st][0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + st * 1024);
-        qf[st][1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + st) * 1024);
-      }
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int c = ks % 3, n2 = (ks + 2) % 3;
-        if (ks < 2) {
-          kf[n2][0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks + 2]);
-          kf[n2][1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks + 2]);
-          qf[n2][0] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (ks + 2) * 1024);
-          qf[n2][1] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + ks + 2) * 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (ks == 0) {
-          if (std::is_same<T, __bf16>::value) {
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sa0) : "v"(kf[c][0]), "v"(qf[c][0]), "v"(A.nm));
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sa1) : "v"(kf[c][1]), "v"(qf[c][0]), "v"(A.nm));
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sb0) : "v"(kf[c][0]), "v"(qf[c][1]), "v"(Bk.nm));
-            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sb1) : "v"(kf[c][1]), "v"(qf[c][1]), "v"(Bk.nm));
-          } else {
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sa0) : "v"(kf[c][0]), "v"(qf[c][0]), "v"(A.nm));
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sa1) : "v"(kf[c][1]), "v"(qf[c][0]), "v"(A.nm));
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sb0) : "v"(kf[c][0]), "v"(qf[c][1]), "v"(Bk.nm));
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sb1) : "v"(kf[c][1]), "v"(qf[c][1]), "v"(Bk.nm));
-          }
-        } else {
-          sa0 = Tr::mfma(kf[c][0], qf[c][0], sa0);
-          sa1 = Tr::mfma(kf[c][1], qf[c][0], sa1);
-          sb0 = Tr::mfma(kf[c][0], qf[c][1], sb0);
-          sb1 = Tr::mfma(kf[c][1], qf[c][1], sb1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else
-#endif
     if (QLDS) {   // Q fragments from the wave's LDS copy, one step ahead like the K fragments
       const unsigned char* ql = smem + Q_OFF + wid * 8192 + lane * 16;
       v8 kc0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[0]);
@@ -436,8 +381,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         if (ks < 3) {
           kn0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks + 1]);
           kn1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks + 1]);
+#ifndef W64_ABL_QREUSE   // timing ablation (WRONG results): what do three quarters of the Q fragment reads cost?
           qan = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (ks + 1) * 1024);
           qbn = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + ks + 1) * 1024);
+#endif
         }
         if (QLDS) __builtin_amdgcn_sched_barrier(0);
         if (QS && ks == 0) {
@@ -570,30 +517,16 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #define TR_STAMP(ev) do { } while (0)
 #endif
   int cur = 0;
-#if defined(W64_YPRIO) && W64_YPRIO == 1
-  if (NW == 8 && wid >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses every age arbitration
-#endif
   for (int t = 0; t < NTILES; ++t) {
     TR_STAMP(0);
     // pair t+RING-1 goes into the slot that was last read in step t-1
-#ifndef W64_ISSUE_AFTER_QK
     if (t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
-#endif
     TR_STAMP(1);
 
     const unsigned char* Kb = smem + K_OFF + cur * TILE_BYTES;
     f32x16 sa0, sa1, sb0, sb1;
     qk_tile(Kb, sa0, sa1, sb0, sb1);
-#ifdef W64_ISSUE_AFTER_QK
-    // behind the QK^T MFMAs: the issue cost of the two transfers (and the segment bookkeeping) falls into the drain
-    // of the matrix pipe instead of the empty stretch after the barrier, where both waves of the SIMD paid it at once
-    if (t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     TR_STAMP(2);
-#if defined(W64_YPRIO) && W64_YPRIO == 2
-    if (NW == 8 && wid >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 
     const int valid = c_len - ct0 * KVB;
     v8 pkA[2][2], pkB[2][2];
@@ -615,7 +548,14 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
           if (key + 32 >= vb) s1[r] = -INFINITY;
         }
       };
-      auto exp_sum = [&](f32x16& s0, f32x16& s1, float (&ts)[4]) {
+      auto pack = [&](f32x16& s0, f32x16& s1, v8 (&pk)[2][2]) {
+        pk[0][0] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+        pk[0][1] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+        pk[1][0] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
+        pk[1][1] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
+      };
+      // exponentials in place, the 16-bit probabilities, and four partial sums of the TILE's row sum
+      auto exp_sum = [&](f32x16& s0, f32x16& s1, float (&ts)[4], v8 (&pk)[2][2]) {
         s0[0] = fast_exp2(s0[0]); s0[1] = fast_exp2(s0[1]); s1[0] = fast_exp2(s1[0]); s1[1] = fast_exp2(s1[1]);
         ts[0] = s0[0]; ts[1] = s0[1]; ts[2] = s1[0]; ts[3] = s1[1];
 #pragma unroll
@@ -624,11 +564,12 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
           s1[r] = fast_exp2(s1[r]); s1[r + 1] = fast_exp2(s1[r + 1]);
           ts[0] += s0[r]; ts[1] += s0[r + 1]; ts[2] += s1[r]; ts[3] += s1[r + 1];
         }
+        pack(s0, s1, pk);
       };
-      auto redo = [&](RowBlock& R, f32x16& s0, f32x16& s1, float (&ts)[4]) {
+      auto redo = [&](RowBlock& R, f32x16& s0, f32x16& s1, float (&ts)[4], v8 (&pk)[2][2]) {
         const float mx = row_max(s0, s1, KVB);   // (masked above)
         const float d = (t == 0) ? mx : max3(mx, 0.f, 0.f);
-        const float alpha = fast_exp2(-d);
+        const float alpha = (t == 0) ? 1.f : fast_exp2(-d);   // first tile: nothing accumulated yet, and 2^-d may be inf
 #pragma unroll
         for (int r = 0; r < 16; ++r) { R.o0[r] *= alpha; R.o1[r] *= alpha; s0[r] -= d; s1[r] -= d; }
         R.la *= alpha;
@@ -637,29 +578,27 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         R.m_run += d;
 #pragma unroll
         for (int r = 0; r < 16; ++r) R.nm[r] = -R.m_run;
-        exp_sum(s0, s1, ts);
+        exp_sum(s0, s1, ts, pk);
       };
       if (valid < KVB) { mask(sa0, sa1); mask(sb0, sb1); }
       float tsA[4], tsB[4];
-      exp_sum(sa0, sa1, tsA);
-      exp_sum(sb0, sb1, tsB);
+#ifdef W64_ABL_NOSM   // timing ablation (WRONG results): no exponentials, no row sums - the matrix skeleton with the packing
+      tsA[0] = tsA[1] = tsA[2] = tsA[3] = tsB[0] = tsB[1] = tsB[2] = tsB[3] = 1.f;
+      pack(sa0, sa1, pkA);
+      pack(sb0, sb1, pkB);
+#else
+      exp_sum(sa0, sa1, tsA, pkA);
+      exp_sum(sb0, sb1, tsB, pkB);
+#endif
       const float big = max3(max3(tsA[0], tsA[1], tsA[2]), max3(tsB[0], tsB[1], tsB[2]), max3(tsA[3], tsB[3], tsB[3]));
       if (t == 0 || __any(!(big <= 2048.f))) {
         qk_tile(Kb, sa0, sa1, sb0, sb1);
         if (valid < KVB) { mask(sa0, sa1); mask(sb0, sb1); }
-        redo(A, sa0, sa1, tsA);
-        redo(Bk, sb0, sb1, tsB);
+        redo(A, sa0, sa1, tsA, pkA);
+        redo(Bk, sb0, sb1, tsB, pkB);
       }
       A.la[0] += tsA[0]; A.la[1] += tsA[1]; A.lb[0] += tsA[2]; A.lb[1] += tsA[3];
       Bk.la[0] += tsB[0]; Bk.la[1] += tsB[1]; Bk.lb[0] += tsB[2]; Bk.lb[1] += tsB[3];
-      pkA[0][0] = __builtin_convertvector(__builtin_shufflevector(sa0, sa0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
-      pkA[0][1] = __builtin_convertvector(__builtin_shufflevector(sa0, sa0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
-      pkA[1][0] = __builtin_convertvector(__builtin_shufflevector(sa1, sa1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
-      pkA[1][1] = __builtin_convertvector(__builtin_shufflevector(sa1, sa1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
-      pkB[0][0] = __builtin_convertvector(__builtin_shufflevector(sb0, sb0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
-      pkB[0][1] = __builtin_convertvector(__builtin_shufflevector(sb0, sb0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
-      pkB[1][0] = __builtin_convertvector(__builtin_shufflevector(sb1, sb1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
-      pkB[1][1] = __builtin_convertvector(__builtin_shufflevector(sb1, sb1, 8, 9, 10, 11, 12, 13, 14, 15), v8);
     } else
 #endif
     {
@@ -668,9 +607,6 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     }
 
     pv_tile(smem + V_OFF + cur * TILE_BYTES, pkA, pkB);
-#if defined(W64_YPRIO) && W64_YPRIO == 2
-    if (NW == 8 && wid >= 4) __builtin_amdgcn_s_setprio(0);
-#endif
     TR_STAMP(3);
     if (++ct0 == c_ntile) {
       if (FOLD) fold_boundary(cseg, t + 1 < NTILES);

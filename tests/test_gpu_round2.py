@@ -258,6 +258,63 @@ def test_prescaled_q_contract(variant, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("case", ["ramp", "jump", "ragged_jump", "far_below_zero"])
+@pytest.mark.parametrize("variant", [13, 11, 17], ids=["w64x8qs", "pipe32", "tp32"])
+def test_reference_checked_after_the_exponentials(variant, case, dtype):
+    """The 64-row pre-scaled-Q kernel takes no row max on ordinary tiles: P = exp2(S - reference) first, and the tile's
+    own row sums say whether a score outgrew the reference (> 2^11 per lane, inf/NaN on overflow); then the scores are
+    formed again and the exact path moves the reference (csrc/shared_attn_fwd_w64.hip).  Inputs that drive that path:
+    scores growing tile after tile ("ramp": a rescale on most tiles), a jump of ~300 exponent units in a late reference
+    ("jump": exp2 overflows to inf before the check), the same behind a ragged tail, and a first tile whose scores
+    all lie far below the initial reference 0.  Against the float64 oracle, default tolerance, LSE included; the other
+    pre-scaled-Q kernels (exact row max) run the same inputs."""
+    from instantrestore_amd import ops
+    B, H, N = 1, 2, 3
+    L, Lr = (4096, 1024) if case != "ragged_jump" else (1000, 333)
+    g = torch.Generator().manual_seed(5 + len(case))
+    C = H * 64
+    c = 0.125 * 1.4426950408889634
+    qp = (torch.randn(B, L, C, generator=g) * c).to(dtype)
+    k, v = torch.randn(B, L, C, generator=g).to(dtype), torch.randn(B, L, C, generator=g).to(dtype)
+    rk, rv = torch.randn(B, N, Lr, C, generator=g).to(dtype), (torch.randn(B, N, Lr, C, generator=g) * 0.7 + 0.1).to(dtype)
+    if case == "ramp":      # |k| grows along the key axis: later tiles hold larger and larger scores
+        k = (k.float() * torch.linspace(0.2, 6.0, L).view(1, L, 1)).to(dtype)
+        rk = (rk.float() * torch.linspace(6.0, 14.0, N * Lr).view(1, N, Lr, 1)).to(dtype)
+    elif case in ("jump", "ragged_jump"):   # one key direction shared by all queries, switched on late and hard
+        d = torch.zeros(C); d[::2] = 1.0
+        qp = (qp.float() + 2.0 * c * d).to(dtype)
+        rk[:, N - 1, Lr - 70:] = (rk[:, N - 1, Lr - 70:].float() + 30.0 * d).to(dtype)
+    else:                   # every score of the walk's first tiles is hugely negative
+        d = torch.ones(C)
+        qp = (qp.float() + 1.5 * c * d).to(dtype)
+        k[:, :256] = (k[:, :256].float() - 20.0 * d).to(dtype)
+    f = lambda t: t.float().numpy().astype(np.float64)
+    rows = torch.arange(0, L, max(1, L // 128))
+    q_equiv = f(qp[:, rows]) / c
+    ref = O.shared_attention_np(q_equiv, f(k), f(v), f(rk), f(rv), H, 0.125, True, True)
+    ops.set_attn_variant(variant)
+    try:
+        aff = ops.adain_stats(v.cuda(), rv.cuda(), heads=H)
+        out, lse = ops.shared_attention(qp.cuda(), k.cuda(), v.cuda(), rk.cuda(), rv.cuda(), heads=H, scale=0.125,
+                                        include_self=True, adain=aff, return_lse=True, q_prescaled=True)
+        name = ops.shared_attention_kernel_name(qp.cuda(), k.cuda(), v.cuda(), rk.cuda(), rv.cuda(), heads=H, scale=0.125,
+                                                include_self=True, adain=aff, q_prescaled=True)
+    finally:
+        ops.set_attn_variant(0)
+    assert {13: "w64", 11: "pipe", 17: "tp"}[variant] in name, name
+    tol = {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+    o = out[:, rows].float().cpu().numpy().astype(np.float64)
+    assert np.isfinite(o).all()
+    assert np.abs(o - ref).max() <= tol * max(1.0, np.abs(ref).max()), np.abs(o - ref).max()
+    qh = O.head_to_batch_dim_np(q_equiv, H)
+    ek, _ = O.extended_kv_np(f(k), f(v), f(rk), f(rv), H, False, True)
+    sc = np.matmul(qh, ek.transpose(0, 2, 1)) * 0.125
+    m = sc.max(-1)
+    lse_ref = (m + np.log(np.exp(sc - m[..., None]).sum(-1))).reshape(B, H, len(rows))
+    assert np.abs(lse[:, :, rows].cpu().numpy() - lse_ref).max() <= 2e-3 * max(1.0, np.abs(lse_ref).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_processor_with_q_prescaled_in_the_projection_epilogue(dtype):
     """At the 64x64-token layer class the fused q/k/v GEMM is this library's own kernel: its q third leaves the epilogue
     as Q * scale * log2(e) (fp32 accumulator * factor, ONE rounding) and the attention runs its pre-scaled-Q form.  Whole

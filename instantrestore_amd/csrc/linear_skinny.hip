@@ -19,6 +19,7 @@ namespace {
 
 constexpr int NCH = 32;                     // columns of Y (rows of W) per chunk
 constexpr int SUB_BYTES = NCH * 128;        // one 64-k sub-tile of a chunk: 32 rows x 128 B
+constexpr int kSkinnyTPitch = 144;          // staging tile row: 128 B (two chunks of a Y row) + 16 B pad
 
 template <typename T, int KS>               // K = 64 * KS
 __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKParams p) {
@@ -26,11 +27,13 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   using v8 = typename Tr::v8;
   using v4 = typename Tr::v4;
   constexpr int CHUNK_BYTES = KS * SUB_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * CHUNK_BYTES];   // two W chunks: one being read, one in flight
-  constexpr int TPITCH = 80;                 // bytes per row of the per-wave output staging tile (64 B + pad)
-  __shared__ __attribute__((aligned(16))) unsigned char tbuf[4 * 64 * TPITCH];
-  __shared__ __attribute__((aligned(16))) T sbias[kLinearMaxBiasN];   // a global bias load inside the loop would make
-                                                                      // hipcc wait on the in-flight W chunk as well
+  // dynamic LDS: two W chunks (one being read, one in flight) | per-wave output staging tiles | bias of this column range
+  // (a global bias load inside the loop would make hipcc wait on the in-flight W chunk as well)
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm_skinny[];
+  unsigned char* const smem = dsm_skinny;
+  constexpr int TPITCH = kSkinnyTPitch;      // bytes per row of a staging tile: TWO chunks = 128 B of a Y row, + pad
+  unsigned char* const tbuf = dsm_skinny + 2 * CHUNK_BYTES;
+  T* const sbias = (T*)(dsm_skinny + 2 * CHUNK_BYTES + 4 * 64 * TPITCH);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -40,7 +43,9 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   // ---- work decode: (row block of 256, range of column chunks) -------------------------------------
   const int mb = blockIdx.x / p.nsplit, sp = blockIdx.x - mb * p.nsplit;
   const int nchunks = p.N / NCH;
-  const int c_begin = (int)(((long)nchunks * sp) / p.nsplit), c_end = (int)(((long)nchunks * (sp + 1)) / p.nsplit);
+  // column ranges start on EVEN chunks when they can: finished chunks leave in pairs, as whole 128-B lines of Y
+  const int unit = (nchunks & 1) ? 1 : 2, nu = nchunks / unit;
+  const int c_begin = unit * (int)(((long)nu * sp) / p.nsplit), c_end = unit * (int)(((long)nu * (sp + 1)) / p.nsplit);
   if (c_begin >= c_end) return;
 
   // ---- X fragments of both 32-row blocks: resident for the whole kernel ------------------------------
@@ -54,7 +59,11 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
       // instead of a separate pass that reads 4 and writes 2 bytes per element ahead of every projection
       // one row block at a time: all 40 fp32 fragments in flight at once would need 320 registers and the allocator
       // answers by spilling resident fragments to scratch (reloaded in the main loop, each reload draining the W stream)
+#ifdef LIN_ABL_L2LOAD   // timing ablation (WRONG results): X rows folded onto the first 1024 - no HBM reads
+      const float* base = (const float*)p.x + hi * 8 - (int64_t)(ra & ~1023) * p.x_ld;
+#else
       const float* base = (const float*)p.x + hi * 8;
+#endif
 #pragma unroll
       for (int ks = 0; ks < 4 * KS; ++ks)
         xA[ks] = __builtin_convertvector(*(const f32x8*)(base + (int64_t)ra * p.x_ld + ks * 16), v8);
@@ -97,12 +106,13 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // A finished chunk (64 rows x 32 columns per wave) leaves through a wave-private LDS tile: in the MFMA
-  // layout a lane owns 4-column groups of ONE row, so direct stores touch 32 rows with 16-32 B each and
-  // the write path drowns in partial-line requests; after the transpose four neighbouring lanes write
-  // the 64 contiguous bytes of a row (16 B each, 16 rows per store instruction).
+  // A finished chunk (64 rows x 32 columns per wave) leaves through a wave-private LDS tile: in the MFMA layout a lane
+  // owns 4-column groups of ONE row, so direct stores touch 32 rows with 16-32 B each and the write path drowns in
+  // partial-line requests.  The tile holds TWO consecutive chunks side by side (64 columns = 128 B per row): after the
+  // transpose eight neighbouring lanes write one whole 128-B line of Y, 8 rows per store instruction.  (Round 2: with
+  // 64-B half lines per chunk the Y stream ran at 2.3 TB/s - each line was written in two halves an iteration apart.)
   unsigned char* tb = tbuf + wid * (64 * TPITCH);
-  auto stage_block = [&](const f32x16& acc, int rbase, int n0) {
+  auto stage_block = [&](const f32x16& acc, int rbase, int n0, int half) {
     const float cs = n0 < p.scale_cols ? p.col_scale : 1.0f;   // leading columns scaled in fp32 before the one rounding
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -114,41 +124,46 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] += (float)bv[i];
       }
-      *(v4*)(tb + (rbase + lq) * TPITCH + (8 * g + 4 * hi) * 2) = __builtin_convertvector(f, v4);
+      *(v4*)(tb + (rbase + lq) * TPITCH + half * 64 + (8 * g + 4 * hi) * 2) = __builtin_convertvector(f, v4);
     }
   };
   // rows past M were loaded as copies of row M-1 and therefore hold row M-1's exact result: they are
   // stored there too (same bytes), which keeps the number of stores per iteration constant - the
   // s_waitcnt arithmetic of the main loop counts them
   const int row0 = mb * 256 + wid * 64;
-  auto store_part = [&](int j, int n0) {   // 16 rows x 64 B: one of the four stores of a finished chunk
+  auto store_full = [&](int j, int n0) {   // 8 rows x 128 B: one of the eight stores of a finished chunk PAIR
+    const int r = 8 * j + (lane >> 3);
+    const u32x4 v = *(const u32x4*)(tb + r * TPITCH + (lane & 7) * 16);
+    const int row = row0 + r;
+#ifdef LIN_ABL_L2STORE   // timing ablation (WRONG results): every store lands in the first 1024 rows of Y - same stream, no HBM writes
+    T* yp = (T*)p.y + (int64_t)((row < p.M ? row : p.M - 1) & 1023) * p.y_ld + n0 + (lane & 7) * 8;
+#else
+    T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 7) * 8;
+#endif
+    *(u32x4*)yp = v;
+  };
+  auto store_half = [&](int j, int n0) {   // 16 rows x 64 B (left half of the tile): a range's odd last chunk
     const int r = 16 * j + (lane >> 2);
     const u32x4 v = *(const u32x4*)(tb + r * TPITCH + (lane & 3) * 16);
     const int row = row0 + r;
     T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 3) * 8;
     *(u32x4*)yp = v;
   };
-  auto store_chunk = [&](const f32x16& a, const f32x16& b, int n0) {
-    stage_block(a, 0, n0);
-    stage_block(b, 32, n0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) store_part(j, n0);
-  };
 
-  // Iteration i: start the transfer of chunk i+1, send chunk i-1's results on their way, compute chunk i,
-  // then wait ONLY for chunk i+1: vector memory operations retire in issue order and the four stores
-  // were issued after it, so they may stay in flight across the barrier.
+  // Iteration i: start the transfer of chunk i+1, put chunk i-1's results into its half of the staging tile and - when
+  // that completes a pair (i even) - send the pair on its way in eight stores issued BETWEEN the MFMA groups of chunk i
+  // (a write path running at HBM speed back-pressures the issuing wave: eight stores in a row stall it and its lockstep
+  // partner workgroup while the matrix pipe idles); compute chunk i; then wait ONLY for chunk i+1: vector memory
+  // operations retire in issue order and the stores were issued after it, so they may stay in flight across the barrier.
   f32x16 accA, accB;
   for (int i = 0; i < ncl; ++i) {
     const int c = c_begin + i, cur = i & 1;
     if (i + 1 < ncl) issue_chunk(c + 1, cur ^ 1);   // its slot was last read in iteration i-1
-    // chunk i-1 leaves in four 16-row stores that are issued BETWEEN the MFMA groups of chunk i: a write
-    // path running at HBM speed back-pressures the issuing wave, and four stores in a row stall it (and
-    // its lockstep partner workgroup) while the matrix pipe idles
     if (i > 0) {
-      stage_block(accA, 0, (c - 1) * NCH);
-      stage_block(accB, 32, (c - 1) * NCH);
+      stage_block(accA, 0, (c - 1) * NCH, (i - 1) & 1);
+      stage_block(accB, 32, (c - 1) * NCH, (i - 1) & 1);
     }
+    const bool pair_done = i > 0 && (i & 1) == 0;   // chunks i-2, i-1 are both in the tile
     const unsigned char* Wb = smem + cur * CHUNK_BYTES;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
@@ -171,20 +186,27 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
         accB = Tr::mfma(wf[s & 1][ks], xB[4 * s + ks], accB);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (i > 0) {   // KS < 4: the remaining parts go out after the last group
-        if (s < 4) store_part(s, (c - 1) * NCH);
-        if (s == KS - 1) {
+      if (pair_done) {   // the eight parts spread over the KS groups
 #pragma unroll
-          for (int j = KS; j < 4; ++j) store_part(j, (c - 1) * NCH);
-        }
+        for (int j = (8 * s) / KS; j < (8 * (s + 1)) / KS; ++j) store_full(j, (c - 2) * NCH);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (i > 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (pair_done) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  store_chunk(accA, accB, (c_end - 1) * NCH);
+  if ((ncl & 1) == 0) {   // the last chunk completes a pair (its partner went into the tile in the last iteration)
+    stage_block(accA, 0, (c_end - 1) * NCH, 1);
+    stage_block(accB, 32, (c_end - 1) * NCH, 1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) store_full(j, (c_end - 2) * NCH);
+  } else {                // odd number of chunks in this range: the last one leaves alone, in half lines
+    stage_block(accA, 0, (c_end - 1) * NCH, 0);
+    stage_block(accB, 32, (c_end - 1) * NCH, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) store_half(j, (c_end - 1) * NCH);
+  }
 }
 
 // K = 640 (the 32x32-token layer class): 64 rows of X no longer fit one wave's registers, so the contraction
@@ -391,6 +413,24 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
   }
 }
 
+template <typename T, int KS>
+hipError_t launch_skinny(const LinearKParams& p, dim3 g, dim3 t, hipStream_t s) {
+  // two W chunks + four staging tiles + the bias of at most N columns: 78 KiB at K = 320 (two workgroups per CU fit
+  // while the bias stays under ~2 KiB, i.e. N <= 960 with bias; wider biased outputs run one workgroup per CU)
+  const size_t dyn = (size_t)2 * KS * SUB_BYTES + 4 * 64 * kSkinnyTPitch + (p.bias != nullptr ? (size_t)p.N * sizeof(T) : 0);
+  static bool attr_set[64] = {};   // per instantiation and per device; idempotent (see the K = 640 launch below)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
+  if (!attr_set[dev]) {
+    hipError_t ea = hipFuncSetAttribute((const void*)linear_skinny_kernel<T, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)((size_t)2 * KS * SUB_BYTES + 4 * 64 * kSkinnyTPitch + kLinearMaxBiasN * sizeof(T)));
+    if (ea != hipSuccess) return ea;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((linear_skinny_kernel<T, KS>), g, t, dyn, s, p);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch(const LinearKParams& p0, hipStream_t s) {
   LinearKParams p = p0;
@@ -417,19 +457,19 @@ hipError_t launch(const LinearKParams& p0, hipStream_t s) {
     return hipGetLastError();
   }
   int nsplit = (512 + mblocks - 1) / mblocks;       // two workgroups per CU
-  if (nsplit > nchunks) nsplit = nchunks;
+  const int nunits = (nchunks & 1) ? nchunks : nchunks / 2;   // ranges start on even chunks when they can (whole-line stores)
+  if (nsplit > nunits) nsplit = nunits;
   if (nsplit < 1) nsplit = 1;
   p.nsplit = nsplit;
   const dim3 g((unsigned)(mblocks * nsplit)), t(256);
   switch (p.K / 64) {
-    case 1: hipLaunchKernelGGL((linear_skinny_kernel<T, 1>), g, t, 0, s, p); break;
-    case 2: hipLaunchKernelGGL((linear_skinny_kernel<T, 2>), g, t, 0, s, p); break;
-    case 3: hipLaunchKernelGGL((linear_skinny_kernel<T, 3>), g, t, 0, s, p); break;
-    case 4: hipLaunchKernelGGL((linear_skinny_kernel<T, 4>), g, t, 0, s, p); break;
-    case 5: hipLaunchKernelGGL((linear_skinny_kernel<T, 5>), g, t, 0, s, p); break;
+    case 1: return launch_skinny<T, 1>(p, g, t, s);
+    case 2: return launch_skinny<T, 2>(p, g, t, s);
+    case 3: return launch_skinny<T, 3>(p, g, t, s);
+    case 4: return launch_skinny<T, 4>(p, g, t, s);
+    case 5: return launch_skinny<T, 5>(p, g, t, s);
     default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
 
 }  // namespace

@@ -21,8 +21,11 @@ constexpr int NCH = 32;                     // columns of Y (rows of W) per chun
 constexpr int SUB_BYTES = NCH * 128;        // one 64-k sub-tile of a chunk: 32 rows x 128 B
 constexpr int kSkinnyTPitch = 144;          // staging tile row: 128 B (two chunks of a Y row) + 16 B pad
 
-template <typename T, int KS>               // K = 64 * KS
-__global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKParams p) {
+// NW waves of 64 rows share every W chunk: 4 (two workgroups per CU) or 8 (one; half the LDS-DMA pieces per wave and
+// half the W traffic from L2 - the form for row counts that fill the chip with 512-row workgroups).  BIAS: compile-time,
+// so that the staging code of the bias-free projections carries no branches.
+template <typename T, int KS, bool BIAS, int NW>   // K = 64 * KS
+__global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
   using v4 = typename Tr::v4;
@@ -33,7 +36,8 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   unsigned char* const smem = dsm_skinny;
   constexpr int TPITCH = kSkinnyTPitch;      // bytes per row of a staging tile: TWO chunks = 128 B of a Y row, + pad
   unsigned char* const tbuf = dsm_skinny + 2 * CHUNK_BYTES;
-  T* const sbias = (T*)(dsm_skinny + 2 * CHUNK_BYTES + 4 * 64 * TPITCH);
+  T* const sbias = (T*)(dsm_skinny + 2 * CHUNK_BYTES + NW * 64 * TPITCH);
+  constexpr int NT = NW * 64;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -49,7 +53,7 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   if (c_begin >= c_end) return;
 
   // ---- X fragments of both 32-row blocks: resident for the whole kernel ------------------------------
-  const int rowA = mb * 256 + wid * 64 + lq, rowB = rowA + 32;
+  const int rowA = mb * NT + wid * 64 + lq, rowB = rowA + 32;
   v8 xA[4 * KS], xB[4 * KS];
   {
     const int ra = rowA < p.M ? rowA : p.M - 1, rb = rowB < p.M ? rowB : p.M - 1;
@@ -84,21 +88,25 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   }
 
   // ---- W chunk stream: 16 B per thread per sub-tile, lane-linear LDS image, swizzle on the source ------
-  const int wrow = tid >> 3, wslot = tid & 7;
+  // a sub-tile (32 rows x 128 B) is four 1-KiB pieces; wave w moves piece (w & 3) of the sub-tiles s = (w >> 2), (w >> 2) + NW/4, ...
+  const int t2 = tid & 255, wq = wid & 3, wh = wid >> 2;   // wave-uniform: the LDS destination of a transfer lives in M0
+  const int wrow = t2 >> 3, wslot = t2 & 7;
   const i32x4 wrw = make_rsrc_words(p.w, (unsigned)(((int64_t)(p.N - 1) * p.w_ld + 64 * KS) * 2));
   const unsigned wvo = (unsigned)(wrow * p.w_ld * 2 + ((wslot ^ ((wrow >> 1) & 7)) * 16));
   auto issue_chunk = [&](int c, int slot) {
     const unsigned off = wvo + (unsigned)((int64_t)c * NCH * p.w_ld * 2);
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
-      buffer_load_lds16_async(wrw, smem + slot * CHUNK_BYTES + s * SUB_BYTES + wid * 1024, off + s * 128);
+    for (int j = 0; j < (KS + NW / 4 - 1) / (NW / 4); ++j) {
+      const int s = j * (NW / 4) + wh;
+      if (s < KS) buffer_load_lds16_async(wrw, smem + slot * CHUNK_BYTES + s * SUB_BYTES + wq * 1024, off + s * 128);
+    }
   };
   int wread[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) wread[ks] = lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4);
 
-  if (p.bias != nullptr)
-    for (int i = tid; i < (c_end - c_begin) * NCH; i += 256) sbias[i] = ((const T*)p.bias)[c_begin * NCH + i];
+  if (BIAS)
+    for (int i = tid; i < (c_end - c_begin) * NCH; i += NT) sbias[i] = ((const T*)p.bias)[c_begin * NCH + i];
   const int ncl = c_end - c_begin;
   issue_chunk(c_begin, 0);
 #pragma unroll
@@ -119,7 +127,7 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
       f32x4 f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) f[i] = acc[4 * g + i] * cs;
-      if (p.bias != nullptr) {
+      if (BIAS) {
         const v4 bv = *(const v4*)(sbias + (n0 - c_begin * NCH) + 8 * g + 4 * hi);
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] += (float)bv[i];
@@ -130,7 +138,7 @@ __global__ void __launch_bounds__(256, 2) linear_skinny_kernel(const LinearKPara
   // rows past M were loaded as copies of row M-1 and therefore hold row M-1's exact result: they are
   // stored there too (same bytes), which keeps the number of stores per iteration constant - the
   // s_waitcnt arithmetic of the main loop counts them
-  const int row0 = mb * 256 + wid * 64;
+  const int row0 = mb * NT + wid * 64;
   auto store_full = [&](int j, int n0) {   // 8 rows x 128 B: one of the eight stores of a finished chunk PAIR
     const int r = 8 * j + (lane >> 3);
     const u32x4 v = *(const u32x4*)(tb + r * TPITCH + (lane & 7) * 16);
@@ -413,22 +421,49 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
   }
 }
 
-template <typename T, int KS>
-hipError_t launch_skinny(const LinearKParams& p, dim3 g, dim3 t, hipStream_t s) {
-  // two W chunks + four staging tiles + the bias of at most N columns: 78 KiB at K = 320 (two workgroups per CU fit
-  // while the bias stays under ~2 KiB, i.e. N <= 960 with bias; wider biased outputs run one workgroup per CU)
-  const size_t dyn = (size_t)2 * KS * SUB_BYTES + 4 * 64 * kSkinnyTPitch + (p.bias != nullptr ? (size_t)p.N * sizeof(T) : 0);
+template <typename T, int KS, bool BIAS, int NW>
+hipError_t launch_skinny2(const LinearKParams& p, int grid, hipStream_t s) {
+  // two W chunks + NW staging tiles + the bias of at most N columns: 78 KiB at K = 320 with 4 waves (two workgroups per CU
+  // fit while the bias stays under ~2 KiB, i.e. N <= 960; wider biased outputs run one workgroup per CU), 114 KiB with 8
+  const size_t fixed = (size_t)2 * KS * SUB_BYTES + (size_t)NW * 64 * kSkinnyTPitch;
+  const size_t dyn = fixed + (BIAS ? (size_t)p.N * sizeof(T) : 0);
   static bool attr_set[64] = {};   // per instantiation and per device; idempotent (see the K = 640 launch below)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
   if (!attr_set[dev]) {
-    hipError_t ea = hipFuncSetAttribute((const void*)linear_skinny_kernel<T, KS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)((size_t)2 * KS * SUB_BYTES + 4 * 64 * kSkinnyTPitch + kLinearMaxBiasN * sizeof(T)));
+    hipError_t ea = hipFuncSetAttribute((const void*)linear_skinny_kernel<T, KS, BIAS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(fixed + (BIAS ? kLinearMaxBiasN * sizeof(T) : 0)));
     if (ea != hipSuccess) return ea;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((linear_skinny_kernel<T, KS>), g, t, dyn, s, p);
+  hipLaunchKernelGGL((linear_skinny_kernel<T, KS, BIAS, NW>), dim3((unsigned)grid), dim3(NW * 64), dyn, s, p);
   return hipGetLastError();
+}
+
+template <typename T, int KS>
+hipError_t launch_skinny(const LinearKParams& p0, hipStream_t s) {
+  LinearKParams p = p0;
+  // 8-wave (512-row, one per CU) workgroups measured SLOWER than two 4-wave ones per CU on every K = 320 shape of the step
+  // (135 vs 119-125 us on 131072 x 960, 52 vs 48 on x 320, 47 vs 44 on 32768 x 960; profiles/r2_kernel_experiments.txt 7):
+  // development builds only (-DIR_ABLATIONS -DLIN_NW8_MIN_M=<rows>)
+#if defined(IR_ABLATIONS) && defined(LIN_NW8_MIN_M)
+  const bool w8 = p.M >= LIN_NW8_MIN_M;
+#else
+  constexpr bool w8 = false;
+#endif
+  const int rows = w8 ? 512 : 256, slots = w8 ? 256 : 512;
+  const int mblocks = (p.M + rows - 1) / rows;
+  const int nchunks = p.N / NCH;
+  int nsplit = (slots + mblocks - 1) / mblocks;
+  const int nunits = (nchunks & 1) ? nchunks : nchunks / 2;   // ranges start on even chunks when they can (whole-line stores)
+  if (nsplit > nunits) nsplit = nunits;
+  if (nsplit < 1) nsplit = 1;
+  p.nsplit = nsplit;
+  const int grid = mblocks * nsplit;
+#if defined(IR_ABLATIONS) && defined(LIN_NW8_MIN_M)
+  if (w8) return p.bias != nullptr ? launch_skinny2<T, KS, true, 8>(p, grid, s) : launch_skinny2<T, KS, false, 8>(p, grid, s);
+#endif
+  return p.bias != nullptr ? launch_skinny2<T, KS, true, 4>(p, grid, s) : launch_skinny2<T, KS, false, 4>(p, grid, s);
 }
 
 template <typename T>
@@ -456,18 +491,12 @@ hipError_t launch(const LinearKParams& p0, hipStream_t s) {
     hipLaunchKernelGGL((linear_ksplit_kernel<T, KSH>), dim3((unsigned)(mblocks * nsplit)), dim3(512), dyn, s, p);
     return hipGetLastError();
   }
-  int nsplit = (512 + mblocks - 1) / mblocks;       // two workgroups per CU
-  const int nunits = (nchunks & 1) ? nchunks : nchunks / 2;   // ranges start on even chunks when they can (whole-line stores)
-  if (nsplit > nunits) nsplit = nunits;
-  if (nsplit < 1) nsplit = 1;
-  p.nsplit = nsplit;
-  const dim3 g((unsigned)(mblocks * nsplit)), t(256);
   switch (p.K / 64) {
-    case 1: return launch_skinny<T, 1>(p, g, t, s);
-    case 2: return launch_skinny<T, 2>(p, g, t, s);
-    case 3: return launch_skinny<T, 3>(p, g, t, s);
-    case 4: return launch_skinny<T, 4>(p, g, t, s);
-    case 5: return launch_skinny<T, 5>(p, g, t, s);
+    case 1: return launch_skinny<T, 1>(p, s);
+    case 2: return launch_skinny<T, 2>(p, s);
+    case 3: return launch_skinny<T, 3>(p, s);
+    case 4: return launch_skinny<T, 4>(p, s);
+    case 5: return launch_skinny<T, 5>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -1,7 +1,12 @@
-mkdir -p gpurun_out/r2i
-python -m pytest tests/test_gpu_linear.py -m gpu -x -q 2>&1 | tail -3
-IR_LIB_PATH=gpurun_lib/libir_N8.so python -m pytest tests/test_gpu_linear.py -m gpu -x -q 2>&1 | tail -3
-for r in 1 2; do for v in N4 N8; do
-  IR_LIB_PATH=gpurun_lib/libir_$v.so python tools/_lin_time.py 2>&1 | grep "K=320"
-done; done 2>&1 | grep -v amdgpu.ids > gpurun_out/r2i/lin4.txt
-sort gpurun_out/r2i/lin4.txt
+mkdir -p gpurun_out/r2j
+R=$PWD
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/r2j/gputest.txt
+python bench.py --steps 20 --warmup 5 > gpurun_out/r2j/bench.json 2> gpurun_out/r2j/bench.err
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r2j/prof_bench -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-extras --two-streams 0 > $R/gpurun_out/r2j/prof_bench.log 2>&1 )
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r2j/smoke.txt 2>&1
+cat gpurun_out/r2j/gputest.txt; tail -2 gpurun_out/r2j/smoke.txt; python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r2j/bench.json").read().strip().splitlines()[-1])
+print(d["value"], d["ms_per_step"], d["roofline"]["achieved"], d["roofline"]["frac"], d["roofline"]["back_to_back"], d["config"]["extras"]["one_stream"], d["config"]["extras"]["hip_graph"]["images_per_s"])
+PY
+head -12 gpurun_out/r2j/prof_bench/b_kernel_stats.csv | cut -c1-150

@@ -70,6 +70,12 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hi = lane >> 5, lq = lane & 31;
+  // Parameters that only the segment changes and the epilogue need are read from the kernel-argument segment THERE,
+  // through a pointer the compiler cannot see through: held in SGPRs across the tile loop (hipcc's choice otherwise) they
+  // pushed the loop's own scalars out into VGPR lanes - v_readlane on every tile
+  typedef const __attribute__((address_space(4))) AttnKParams* KArgs;
+  const KArgs kargs = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  auto cold = [&]() -> KArgs { KArgs q = kargs; asm volatile("" : "+s"(q)); return q; };
 
   // ---- work decode (whole items, then K/V-range pieces of the remainder items) -------------------
   const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
@@ -128,18 +134,19 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   int kstep = 0, vstep = 0, sntile = 0, seg = 0, t0 = 0;
   unsigned kvo[CH], vvo[CH];
   auto seg_setup = [&](int s) {
+    const KArgs c = cold();
     const T* sk;
     const T* sv;
     int ksl_b, vsl_b, slen;
-    if (p.include_self && s == 0) {
-      sk = (const T*)p.k_self + (int64_t)b * p.ks_sb + (int64_t)h * p.ks_sh;
-      sv = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
-      ksl_b = (int)p.ks_sl * 2; vsl_b = (int)p.vs_sl * 2; slen = p.Ls; sntile = p.tiles_self;
+    if (c->include_self && s == 0) {
+      sk = (const T*)c->k_self + (int64_t)b * c->ks_sb + (int64_t)h * c->ks_sh;
+      sv = (const T*)c->v_self + (int64_t)b * c->vs_sb + (int64_t)h * c->vs_sh;
+      ksl_b = (int)c->ks_sl * 2; vsl_b = (int)c->vs_sl * 2; slen = c->Ls; sntile = c->tiles_self;
     } else {
-      const int n = s - p.include_self;
-      sk = (const T*)p.k_ref + (int64_t)b * p.kr_sb + (int64_t)n * p.kr_sn + (int64_t)h * p.kr_sh;
-      sv = (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)n * p.vr_sn + (int64_t)h * p.vr_sh;
-      ksl_b = (int)p.kr_sl * 2; vsl_b = (int)p.vr_sl * 2; slen = p.Lr; sntile = p.tiles_ref;
+      const int n = s - c->include_self;
+      sk = (const T*)c->k_ref + (int64_t)b * c->kr_sb + (int64_t)n * c->kr_sn + (int64_t)h * c->kr_sh;
+      sv = (const T*)c->v_ref + (int64_t)b * c->vr_sb + (int64_t)n * c->vr_sn + (int64_t)h * c->vr_sh;
+      ksl_b = (int)c->kr_sl * 2; vsl_b = (int)c->vr_sl * 2; slen = c->Lr; sntile = c->tiles_ref;
     }
     krw = make_rsrc_words(sk, (unsigned)((slen - 1) * ksl_b + 128));
     vrw = make_rsrc_words(sv, (unsigned)((slen - 1) * vsl_b + 128));
@@ -316,18 +323,19 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   };
   auto fold_boundary = [&](int sc, bool has_next) {
     const float lsA = seg_row_sum(A), lsB = seg_row_sum(Bk);
-    const bool cur_ref = !(p.include_self && sc == 0);
-    const int64_t ao_c = ((int64_t)(b * p.N + (cur_ref ? sc - p.include_self : 0)) * p.H + h) * 64 + 4 * hi;
-    const int64_t ao_n = ((int64_t)(b * p.N + (has_next ? sc + 1 - p.include_self : 0)) * p.H + h) * 64 + 4 * hi;
+    const KArgs c = cold();
+    const bool cur_ref = !(c->include_self && sc == 0);
+    const int64_t ao_c = ((int64_t)(b * c->N + (cur_ref ? sc - c->include_self : 0)) * c->H + h) * 64 + 4 * hi;
+    const int64_t ao_n = ((int64_t)(b * c->N + (has_next ? sc + 1 - c->include_self : 0)) * c->H + h) * 64 + 4 * hi;
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 ac0 = {1.f, 1.f, 1.f, 1.f}, ac1 = ac0, an0 = ac0, an1 = ac0, bc0 = {0.f, 0.f, 0.f, 0.f}, bc1 = bc0;
       if (cur_ref) {
-        ac0 = *(const f32x4*)(p.aa + ao_c + 8 * g4); ac1 = *(const f32x4*)(p.aa + ao_c + 32 + 8 * g4);
-        bc0 = *(const f32x4*)(p.ab + ao_c + 8 * g4); bc1 = *(const f32x4*)(p.ab + ao_c + 32 + 8 * g4);
+        ac0 = *(const f32x4*)(c->aa + ao_c + 8 * g4); ac1 = *(const f32x4*)(c->aa + ao_c + 32 + 8 * g4);
+        bc0 = *(const f32x4*)(c->ab + ao_c + 8 * g4); bc1 = *(const f32x4*)(c->ab + ao_c + 32 + 8 * g4);
       }
       if (has_next) {
-        an0 = *(const f32x4*)(p.aa + ao_n + 8 * g4); an1 = *(const f32x4*)(p.aa + ao_n + 32 + 8 * g4);
+        an0 = *(const f32x4*)(c->aa + ao_n + 8 * g4); an1 = *(const f32x4*)(c->aa + ao_n + 32 + 8 * g4);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -610,7 +618,8 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     TR_STAMP(3);
     if (++ct0 == c_ntile) {
       if (FOLD) fold_boundary(cseg, t + 1 < NTILES);
-      ct0 = 0; ++cseg; c_ntile = p.tiles_ref; c_len = p.Lr;
+      const KArgs c = cold();
+      ct0 = 0; ++cseg; c_ntile = c->tiles_ref; c_len = c->Lr;
     }
 
     // pair t+1 has landed; with RING = 3 the 2*CH transfers of pair t+2, issued in this step, stay in flight

@@ -627,7 +627,9 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     if (RING == 3 && t + 2 < NTILES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     TR_STAMP(4);
+#ifndef W64_ABL_NOBAR   // timing ablation (racy, WRONG results): what does the per-tile barrier cost?
     __syncthreads();
+#endif
     cur = (RING == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
   }
 #ifdef W64_TRACE

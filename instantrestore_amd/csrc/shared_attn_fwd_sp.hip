@@ -105,7 +105,10 @@ __device__ __forceinline__ void sp_vec(float s0, float s1, float c2, float nmc, 
   "v_fma_f32 %[t1], %[s1], %[c2], %[nmc]\n\t"
 #define IR_SP_OUT [t0] "=&v"(t0), [t1] "=&v"(t1), [l0] "+v"(l0), [l1] "+v"(l1), [pk] "=v"(pk), [mx] "+v"(mx)
 #define IR_SP_IN [s0] "v"(s0), [s1] "v"(s1), [m0] "v"(m0), [m1] "v"(m1), [hold] "v"(hold)
-  if (PRESC) {
+  if (SP_ABL & 128) {   // timing ablation: five vector instructions per gap (no multiply-add, no row max) - the pre-scaled, check-after form
+    asm volatile("v_exp_f32 %[t0], %[s0]\n\tv_exp_f32 %[t1], %[s1]\n\tv_add_f32 %[l0], %[l0], %[t0]\n\tv_add_f32 %[l1], %[l1], %[t1]\n\tv_cvt_pk_bf16_f32 %[pk], %[t0], %[t1]"
+                 : IR_SP_OUT : IR_SP_IN);
+  } else if (PRESC) {
     if (BF) asm volatile(IR_SP_REST("v_cvt_pk_bf16_f32", "%[s0]", "%[s1]") : IR_SP_OUT : IR_SP_IN);
     else asm volatile(IR_SP_REST("v_cvt_pk_f16_f32", "%[s0]", "%[s1]") : IR_SP_OUT : IR_SP_IN);
   } else {

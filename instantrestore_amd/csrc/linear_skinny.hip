@@ -163,14 +163,26 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
   // (a write path running at HBM speed back-pressures the issuing wave: eight stores in a row stall it and its lockstep
   // partner workgroup while the matrix pipe idles); compute chunk i; then wait ONLY for chunk i+1: vector memory
   // operations retire in issue order and the stores were issued after it, so they may stay in flight across the barrier.
+#ifdef LIN_TRACE
+  // development aid: the four waves of workgroup 0 stamp s_memtime at the phase boundaries of chunks 4..19 into the bias
+  // region of LDS (bias-free launches only); dumped into the head of Y at the end (tools/gpu_lin_trace.py)
+#define LT_STAMP(ev) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && i >= 4 && i < 20 && lane == 0) \
+    ((IR_LDS unsigned*)(IR_LDS unsigned char*)sbias)[(wid * 16 + (i - 4)) * 8 + (ev)] = (unsigned)__builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LT_STAMP(ev) do { } while (0)
+#endif
   f32x16 accA, accB;
   for (int i = 0; i < ncl; ++i) {
     const int c = c_begin + i, cur = i & 1;
+    LT_STAMP(0);
     if (i + 1 < ncl) issue_chunk(c + 1, cur ^ 1);   // its slot was last read in iteration i-1
+    LT_STAMP(1);
     if (i > 0) {
       stage_block(accA, 0, (c - 1) * NCH, (i - 1) & 1);
       stage_block(accB, 32, (c - 1) * NCH, (i - 1) & 1);
     }
+    LT_STAMP(2);
     const bool pair_done = i > 0 && (i & 1) == 0;   // chunks i-2, i-1 are both in the tile
     const unsigned char* Wb = smem + cur * CHUNK_BYTES;
 #pragma unroll
@@ -200,10 +212,19 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    LT_STAMP(3);
     if (pair_done) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LT_STAMP(4);
     __syncthreads();
   }
+#ifdef LIN_TRACE
+  if (blockIdx.x == 0 && !BIAS) {
+    __syncthreads();
+    for (int j = tid; j < 4 * 16 * 8; j += NT) ((unsigned*)p.y)[j] = ((IR_LDS unsigned*)(IR_LDS unsigned char*)sbias)[j];
+    return;
+  }
+#endif
   if ((ncl & 1) == 0) {   // the last chunk completes a pair (its partner went into the tile in the last iteration)
     stage_block(accA, 0, (c_end - 1) * NCH, 1);
     stage_block(accB, 32, (c_end - 1) * NCH, 1);
@@ -426,7 +447,11 @@ hipError_t launch_skinny2(const LinearKParams& p, int grid, hipStream_t s) {
   // two W chunks + NW staging tiles + the bias of at most N columns: 78 KiB at K = 320 with 4 waves (two workgroups per CU
   // fit while the bias stays under ~2 KiB, i.e. N <= 960; wider biased outputs run one workgroup per CU), 114 KiB with 8
   const size_t fixed = (size_t)2 * KS * SUB_BYTES + (size_t)NW * 64 * kSkinnyTPitch;
+#ifdef LIN_TRACE
+  const size_t dyn = fixed + 4096;
+#else
   const size_t dyn = fixed + (BIAS ? (size_t)p.N * sizeof(T) : 0);
+#endif
   static bool attr_set[64] = {};   // per instantiation and per device; idempotent (see the K = 640 launch below)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;

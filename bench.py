@@ -406,6 +406,34 @@ def extra_scatter_gather(B_local, N, px, world, rank, dev, backend):
             "bytes_per_identity": (1 + N) * 3 * px * px * 2 + 3 * px * px * 2, "ok": bool(ok)}
 
 
+def _guarded(fn, dev, seconds):
+    """Run ``fn`` - inline when ``seconds`` is None, else in a helper thread joined with a timeout.  Returns (result or
+    {"error": ...}, timed_out).  A collective that never returns cannot be interrupted; the caller then skips every
+    further collective and leaves through os._exit once its line is printed."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            if dev is not None and dev.type == "cuda":
+                torch.cuda.set_device(dev)
+            if os.environ.get("IR_BENCH_SG_HANG") == str(int(os.environ.get("RANK", "0"))):   # test hook: this rank stalls
+                time.sleep(1e6)
+            box["r"] = fn()
+        except Exception as e:
+            box["r"] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    if seconds is None:
+        run()
+        return box.get("r"), False
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return {"error": "no result after %.0f s (watchdog)" % seconds}, True
+    return box.get("r"), False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -516,6 +544,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(N, px, train_input, use_adain, seed=99)
     extras = None
+    hung = False
     if not args.no_extras:
         extras = {}
         if rank == 0:
@@ -549,13 +578,13 @@ def main():
                         extras["e2e_topology_host"] = extra_e2e(B, N, px, dtype, max(2, args.steps // 2), dev)
                     except Exception as e:
                         extras["e2e_topology_host"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        try:
-            sg = extra_scatter_gather(B, N, px, world, rank, dev, backend)
-        except Exception as e:
-            sg = {"error": "%s: %s" % (type(e).__name__, e)}
+        # The collective extra must never cost the headline (measured above): with N > 1 it runs under a watchdog - a rank
+        # that fails or stalls inside RCCL would otherwise leave the others waiting in their transfers for ever
+        sg, hung = _guarded(lambda: extra_scatter_gather(B, N, px, world, rank, dev, backend), dev,
+                            float(os.environ.get("IR_BENCH_SG_TIMEOUT", "120")) if world > 1 else None)
         extras["scatter_gather"] = sg
-    if world > 1:
-        dist.barrier()
+    if world > 1 and not hung:
+        _, hung = _guarded(lambda: dist.barrier(), dev, 60.0)
 
     if rank == 0:
         from instantrestore_amd.roofline import summary
@@ -595,6 +624,11 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
+        if hung:   # some rank is stuck in a collective: the line is out, leave without the teardown that would wait for it
+            sys.stdout.flush()
+            sys.stderr.write("bench.py: rank %d leaves without process-group teardown (collective extra timed out)\n" % rank)
+            sys.stderr.flush()
+            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -61,3 +61,25 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16
     assert abs(d["value"] - 16 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
     assert d["cpu_baseline"] is None and d["config"]["parallelism"].startswith("dp2")
+
+
+@pytest.mark.gpu
+def test_bench_line_survives_a_rank_that_stalls_in_the_collective_extra():
+    """The scatter/gather extra runs after the headline measurement and under a watchdog when N > 1: if a rank stalls
+    inside it (test hook: rank 1 never enters), rank 0 still prints its one line - with the error recorded where the
+    extra's result would be - and every rank leaves with exit code 0 instead of waiting in a collective for ever."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, IR_BENCH_DIST_BACKEND="gloo", IR_BENCH_SHARE_DEVICE="1", IR_BENCH_SG_HANG="1", IR_BENCH_SG_TIMEOUT="8")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(REPO, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-roofline"],
+                       capture_output=True, text=True, cwd=REPO, timeout=900, env=env)
+    assert r.returncode == 0, (r.stderr + r.stdout)[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert "error" in d["config"]["extras"]["scatter_gather"]

@@ -376,6 +376,8 @@ def extra_scatter_gather(B_local, N, px, world, rank, dev, backend):
     """the batch scatter (degraded + references, fp16) and the output gather as grouped point-to-point
     transfers over the process group - RCCL send/recv when N > 1 - outside the headline timing."""
     from instantrestore_amd import sharding
+    if os.environ.get("IR_BENCH_SG_HANG") == str(rank):   # test hook: this rank never enters the transfers
+        time.sleep(1e6)
     total = B_local * world
     dt = torch.float16
     if backend != "nccl" and world > 1:
@@ -417,8 +419,6 @@ def _guarded(fn, dev, seconds):
         try:
             if dev is not None and dev.type == "cuda":
                 torch.cuda.set_device(dev)
-            if os.environ.get("IR_BENCH_SG_HANG") == str(int(os.environ.get("RANK", "0"))):   # test hook: this rank stalls
-                time.sleep(1e6)
             box["r"] = fn()
         except Exception as e:
             box["r"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -580,8 +580,13 @@ def main():
                         extras["e2e_topology_host"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # The collective extra must never cost the headline (measured above): with N > 1 it runs under a watchdog - a rank
         # that fails or stalls inside RCCL would otherwise leave the others waiting in their transfers for ever
-        sg, hung = _guarded(lambda: extra_scatter_gather(B, N, px, world, rank, dev, backend), dev,
-                            float(os.environ.get("IR_BENCH_SG_TIMEOUT", "120")) if world > 1 else None)
+        if world > 1:   # rank 0 has just run the single-rank extras: the others wait for it HERE, not inside the timed extra
+            _, hung = _guarded(lambda: dist.barrier(), dev, 900.0)
+        if hung:
+            sg = {"error": "skipped: the ranks did not meet at the barrier before it"}
+        else:
+            sg, hung = _guarded(lambda: extra_scatter_gather(B, N, px, world, rank, dev, backend), dev,
+                                float(os.environ.get("IR_BENCH_SG_TIMEOUT", "120")) if world > 1 else None)
         extras["scatter_gather"] = sg
     if world > 1 and not hung:
         _, hung = _guarded(lambda: dist.barrier(), dev, 60.0)

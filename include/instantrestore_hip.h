@@ -50,8 +50,9 @@ typedef enum ir_dtype { IR_DTYPE_F16 = 0, IR_DTYPE_BF16 = 1 } ir_dtype;
                                    fp32 accumulator before the one rounding to 16 bit, ir_linear_fwd col_scale): the
                                    scores leave the matrix pipe in the exp2 domain and the kernel saves one multiply-add
                                    per score.  `scale` is still the reference's attn.scale (used for the LSE). */
-#define IR_FLAG_OUT_F32 4u      /* out is fp32 (strides in fp32 elements): the kernel's result BEFORE the rounding to the
-                                   16-bit type - parity instrumentation (tests show the pre-rounding error) */
+#define IR_FLAG_OUT_F32 4u      /* out is fp32 (strides in fp32 elements): the result of the SAME kernel the call would launch
+                                   otherwise, stored BEFORE its rounding to the 16-bit type - parity instrumentation
+                                   (tests show the pre-rounding error of the kernel that ships) */
 
 /*
  * ir_shared_attn_fwd - fused extended self-attention (flash-style, no probability matrix).
@@ -120,8 +121,8 @@ typedef struct ir_shared_attn_args {
 #define IR_TUNE_W64X4 12
 #define IR_TUNE_W64X8 13
 #define IR_TUNE_PIPE32_EARLYQK 14
-#define IR_TUNE_SP64 16
-#define IR_TUNE_TP32 17
+#define IR_TUNE_SP64 16   /* development builds (-DIR_ABLATIONS) only: the one-wave-per-SIMD experiment */
+#define IR_TUNE_TP32 17   /* development builds (-DIR_ABLATIONS) only: the three-stage 32-row experiment */
 
 /*
  * Scratch for the remainder split: when the number of (batch, head, query-block) work items is not

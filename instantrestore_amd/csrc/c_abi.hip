@@ -65,10 +65,8 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->include_self = inc ? 1 : 0;
   p->q_prescaled = (a->flags & IR_FLAG_Q_PRESCALED) ? 1 : 0;
   p->out_f32 = (a->flags & IR_FLAG_OUT_F32) ? 1 : 0;
-  if (p->out_f32 && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_SP64)
-    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_OUT_F32 is implemented by the SP64 kernel only");
-  if (p->q_prescaled && (p->out_f32 || (a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q && a->tuning != IR_TUNE_TP32)))
-    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8 and PIPE32_PRESCALE_Q kernels only (and not with IR_FLAG_OUT_F32)");
+  if (p->q_prescaled && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q && a->tuning != IR_TUNE_TP32)
+    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8 and PIPE32_PRESCALE_Q kernels only");
   p->tiles_self = inc ? (a->len_self + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->tiles_ref = a->n_refs > 0 ? (a->len_ref + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->ntiles = p->tiles_self + a->n_refs * p->tiles_ref;

@@ -426,7 +426,7 @@ bool ir_attn_variant_available(int variant) {
   return base <= 17;
 #else
   if ((variant >> 5) != 0) return false;
-  return base == 0 || base == 7 || (base >= 10 && base <= 14) || base == 16 || base == 17;
+  return base == 0 || base == 7 || (base >= 10 && base <= 14);   // 16 (SP64) and 17 (TP32): development builds, like 1-6, 8, 9, 15
 #endif
 }
 
@@ -455,16 +455,18 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   }
 #endif
   const int base = variant & 31;
-  // fp32 output: the one-wave-per-SIMD kernel only; pre-scaled Q: the 64-row kernel's QS instantiation where the default
-  // rule (or IR_TUNE_W64X8) takes that kernel, the 32-row kernel's reference-through-C form for every other shape
-  if (p.out_f32) return ir_launch_shared_attn_fwd_sp(p, dtype, s);
-  if (base == 17 && !p.out_f32) return ir_launch_shared_attn_fwd_tp(p, dtype, s);
+  // pre-scaled Q: the 64-row kernel's QS instantiation where the default rule (or IR_TUNE_W64X8) takes that kernel, the
+  // 32-row kernel's reference-through-C form for every other shape.  fp32 output (IR_FLAG_OUT_F32): every product kernel
+  // stores its result before the rounding when asked - what the parity tests look at is the kernel that ships
+#ifdef IR_ABLATIONS
+  if (base == 17) return ir_launch_shared_attn_fwd_tp(p, dtype, s);
+  if (base == 16) return ir_launch_shared_attn_fwd_sp(p, dtype, s);
+#endif
   if (p.q_prescaled) {
     if ((base == 0 && ir_attn_default_is_w64(p)) || base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
     return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);   // the 32-row kernel's pre-scaled-Q form, minus its own Q rounding
   }
   switch (base) {
-    case 16: return ir_launch_shared_attn_fwd_sp(p, dtype, s);
     case 0:
       if (ir_attn_default_is_w64(p)) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
       return ir_launch_shared_attn_fwd_pipe(p, dtype, 14, s);

@@ -542,7 +542,9 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
   }
   const float inv = 1.0f / l_fin;
   if (qrow < p.Lq) {
-    T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh;
+    const int64_t ooff = (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh;
+    T* op = (T*)p.out + ooff;
+    float* of = (float*)p.out + ooff;   // IR_FLAG_OUT_F32: the result before the 16-bit rounding (strides in fp32 elements)
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
       f32x4 x0, x1;
@@ -552,8 +554,13 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
         x0[i] = (FOLD ? ot_lds[r * NT] : o0[r]) * inv;
         x1[i] = (FOLD ? ot_lds[(16 + r) * NT] : o1[r]) * inv;
       }
-      *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
-      *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
+      if (p.out_f32) {
+        *(f32x4*)(of + 8 * g4 + 4 * hi) = x0;
+        *(f32x4*)(of + 32 + 8 * g4 + 4 * hi) = x1;
+      } else {
+        *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
+        *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
+      }
     }
     if (p.lse != nullptr && hi == 0)
       p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = (PRESC ? m_run * 0.69314718f : m_run * p.scale) + __logf(l_fin);

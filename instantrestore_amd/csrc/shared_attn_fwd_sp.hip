@@ -26,6 +26,8 @@
 //     per tile.
 // PRESC (IR_FLAG_Q_PRESCALED): Q arrives as Q*scale*log2(e), the running reference enters through the C operand
 // of the first QK^T MFMA of a tile, the scores leave the matrix pipe as exponents: no multiply-add per score.
+#ifdef IR_ABLATIONS   // documented experiment (variant 16): development builds only
+
 #include <type_traits>
 
 #include "ir_common.h"
@@ -639,3 +641,5 @@ hipError_t launch_t(const AttnKParams& p, hipStream_t s) {
 hipError_t ir_launch_shared_attn_fwd_sp(const AttnKParams& p, int dtype, hipStream_t s) {
   return dtype == 1 ? launch_t<__bf16>(p, s) : launch_t<_Float16>(p, s);
 }
+
+#endif  // IR_ABLATIONS

@@ -20,6 +20,8 @@
 // scaled exactly once.  The AdaIN segment boundary is delayed the same way (`fold_pend`).
 // Each cluster = two adjacent volatile asm statements (see shared_attn_fwd_sp.hip for why not builtins).
 // 8 waves = 256 query rows per workgroup, one workgroup per CU; K and V rings of 2 tiles, LDS-DMA one iteration ahead.
+#ifdef IR_ABLATIONS   // documented experiment (variant 17, DESIGN.md 4.1b'): development builds only
+
 #include <type_traits>
 
 #include "ir_common.h"
@@ -559,3 +561,5 @@ hipError_t launch_t(const AttnKParams& p, hipStream_t s) {
 hipError_t ir_launch_shared_attn_fwd_tp(const AttnKParams& p, int dtype, hipStream_t s) {
   return dtype == 1 ? launch_t<__bf16>(p, s) : launch_t<_Float16>(p, s);
 }
+
+#endif  // IR_ABLATIONS

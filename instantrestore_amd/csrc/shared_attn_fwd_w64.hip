@@ -677,14 +677,21 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     }
     const float inv = 1.0f / l_fin;
     if (qrow < p.Lq) {
-      T* op = (T*)p.out + (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh;
+      const int64_t ooff = (int64_t)b * p.o_sb + (int64_t)qrow * p.o_sl + (int64_t)h * p.o_sh;
+      T* op = (T*)p.out + ooff;
+      float* of = (float*)p.out + ooff;   // IR_FLAG_OUT_F32: the result before the 16-bit rounding (strides in fp32 elements)
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
         f32x4 x0, x1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { x0[i] = R.o0[4 * g4 + i] * inv; x1[i] = R.o1[4 * g4 + i] * inv; }
-        *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
-        *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
+        if (p.out_f32) {
+          *(f32x4*)(of + 8 * g4 + 4 * hi) = x0;
+          *(f32x4*)(of + 32 + 8 * g4 + 4 * hi) = x1;
+        } else {
+          *(v4*)(op + 8 * g4 + 4 * hi) = __builtin_convertvector(x0, v4);
+          *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
+        }
       }
 #if !defined(W64_PP_TRACE) && !defined(W64_TRACE)
       if (p.lse != nullptr && hi == 0)

@@ -36,10 +36,10 @@ def _np64(t):
     return None if t is None else t.float().cpu().numpy().astype(np.float64)
 
 
-# kernels of the product library (per-call `tuning` field of the C ABI; the documented experiments 1/2/3/4/6/8/9/15 exist
-# only in -DIR_ABLATIONS development builds and are not part of this matrix)
-VARIANTS = [0, 7, 10, 11, 12, 13, 14, 16, 17]
-VARIANT_IDS = ["default", "pipe32exactmax", "pipe32", "pipe32prescaleq", "w64x4", "w64x8", "pipe32earlyqk", "sp64", "tp32"]
+# kernels of the product library (per-call `tuning` field of the C ABI; the documented experiments 1/2/3/4/6/8/9/15/16/17
+# exist only in -DIR_ABLATIONS development builds and are not part of this matrix)
+VARIANTS = [0, 7, 10, 11, 12, 13, 14]
+VARIANT_IDS = ["default", "pipe32exactmax", "pipe32", "pipe32prescaleq", "w64x4", "w64x8", "pipe32earlyqk"]
 
 # variant 11 ("prescaledq", opt-in): Q is multiplied by scale*log2(e) and rounded to the 16-bit type once
 # more before the QK^T MFMAs - one extra input rounding, stated as twice the default tolerance
@@ -476,7 +476,7 @@ def test_hip_graph_capture_and_replay(ops):
     assert torch.equal(y, want)
 
 
-@pytest.mark.parametrize("variant", [0, 7, 11, 12, 16, 17])
+@pytest.mark.parametrize("variant", [0, 7, 11, 12, 13])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 def test_absolute_accuracy_on_unit_normal_activations(ops, dtype, variant, capsys):
     """BASELINE.json's north_star tolerance is 'max-abs 1e-3' on the attention output; it is
@@ -516,7 +516,7 @@ def test_training_mode_is_refused_loudly(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
-@pytest.mark.parametrize("variant", [0, 12, 13, 16, 17], ids=["default", "w64x4", "w64x8", "sp64", "tp32"])
+@pytest.mark.parametrize("variant", [0, 12, 13], ids=["default", "w64x4", "w64x8"])
 def test_massive_activation_channels(ops, dtype, variant):
     """diffusion UNets carry a few channels that are tens of times larger than the rest: scores with a
     heavy tail (lazy max must still move when it has to), reference V with an outlier channel (AdaIN

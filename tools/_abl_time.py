@@ -7,7 +7,7 @@ B, L, C, H, N = 8, 4096, 320, 5, 4
 torch.manual_seed(0)
 q, k, v = (torch.randn(B, L, C, device="cuda").to(torch.bfloat16) for _ in range(3))
 rk = torch.randn(B, N, L, C, device="cuda").to(torch.bfloat16); rv = torch.randn(B, N, L, C, device="cuda").to(torch.bfloat16)
-ops.set_attn_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 16)
+ops.set_attn_variant(int(sys.argv[1]) if len(sys.argv) > 1 else 13)
 presc = len(sys.argv) > 2 and sys.argv[2] == "presc"
 kw = dict(heads=H, scale=0.125, include_self=True, q_prescaled=presc)
 if "adain" in sys.argv: kw["adain"] = ops.adain_stats(v, rv, heads=H)

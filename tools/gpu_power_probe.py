@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from instantrestore_amd import ops
 
-variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "13,16").split(",")]
+variants = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "13").split(",")]
 PRESC = len(sys.argv) > 3 and sys.argv[3] == "presc"   # also run every variant with IR_FLAG_Q_PRESCALED
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 3.0
 B, N, L, H = 8, 4, 4096, 5

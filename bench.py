@@ -91,14 +91,14 @@ _REF_STREAM = {}
 _AUTOCAST = {"dtype": None}   # set by main(): the 16-bit compute dtype the step autocasts to (None: inputs already 16 bit)
 
 
-def hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached_kv=None):
+def hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached_kv=None, return_kv=False):
     if _AUTOCAST["dtype"] is None:
-        return _hot_path_step(layers, B, N, ref_early_exit, two_streams, cached_kv)
+        return _hot_path_step(layers, B, N, ref_early_exit, two_streams, cached_kv, return_kv)
     with torch.autocast("cuda", dtype=_AUTOCAST["dtype"]):
-        return _hot_path_step(layers, B, N, ref_early_exit, two_streams, cached_kv)
+        return _hot_path_step(layers, B, N, ref_early_exit, two_streams, cached_kv, return_kv)
 
 
-def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached_kv=None):
+def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached_kv=None, return_kv=False):
     """one pass: K/V capture -> harvest -> shared attention.  Returns the 9 outputs.
     ``cached_kv`` = (keys, values): the reference branch is skipped (per-identity K/V cache).
 
@@ -142,6 +142,8 @@ def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached
                                     ref_events=events if two_streams else None))
     if two_streams:
         cur.wait_stream(ref_stream)
+    if return_kv:      # determinism checks compare the harvested K/V lists too
+        return outs, keys, vals
     return outs
 
 
@@ -284,28 +286,71 @@ def _time_steps(fn, steps, warm=3):
     return (time.perf_counter() - t0) / steps
 
 
+class CapturedStep:
+    """the whole two-stream step captured once in ONE hipGraph (fork / join through the processors' events); ``replay()``
+    re-runs it, ``outs`` / ``keys`` / ``vals`` are the graph's static result tensors"""
+
+    def __init__(self, layers, B, N):
+        self.graph = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        saved = dict(_REF_STREAM)
+        with torch.cuda.stream(s):
+            _REF_STREAM.clear()
+            hot_path_step(layers, B, N, False, True)     # side stream + per-stream workspaces exist before the capture
+            torch.cuda.synchronize()
+            with torch.cuda.graph(self.graph, stream=s):
+                self.outs, self.keys, self.vals = hot_path_step(layers, B, N, False, True, return_kv=True)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        _REF_STREAM.clear()
+        _REF_STREAM.update(saved)
+
+    def replay(self):
+        self.graph.replay()
+
+
+def determinism_report(layers, B, N, reps=10):
+    """The step run three ways - one stream, two streams, two streams replayed from one hipGraph - ``reps`` times each;
+    every layer output and every harvested K/V tensor is compared bit for bit (``torch.equal``) with the first one-stream
+    run.  The reference runs one stream (inference/test.py:79-111), i.e. deterministically: so must every schedule here."""
+    def snap(res):
+        outs, keys, vals = res
+        return [t.clone() for t in list(outs) + list(keys) + list(vals)]
+    n = len(layers)
+    names = ["out%d" % i for i in range(n)] + ["key%d" % i for i in range(n)] + ["val%d" % i for i in range(n)]
+    base = snap(hot_path_step(layers, B, N, False, False, return_kv=True))
+    torch.cuda.synchronize()
+    cap = CapturedStep(layers, B, N)
+    runs = {
+        "one_stream": lambda: hot_path_step(layers, B, N, False, False, return_kv=True),
+        "two_streams": lambda: hot_path_step(layers, B, N, False, True, return_kv=True),
+        "hip_graph": lambda: (cap.replay(), (cap.outs, cap.keys, cap.vals))[1],
+    }
+    report = {}
+    for mode, fn in runs.items():
+        bad = {}
+        for _ in range(reps):
+            got = fn()
+            torch.cuda.synchronize()
+            for name, t, b in zip(names, list(got[0]) + list(got[1]) + list(got[2]), base):
+                if not torch.equal(t, b):
+                    bad[name] = max(bad.get(name, 0.0), float((t.float() - b.float()).abs().max()))
+            del got
+        report[mode] = {"runs": reps, "identical": not bad, "mismatching": bad}
+    del cap
+    return report
+
+
 def extra_graph(layers, B, N, steps):
     """the whole two-stream step captured in ONE hipGraph and replayed: same launches, same work, no CPU launch gaps"""
-    g = torch.cuda.CUDAGraph()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    saved = dict(_REF_STREAM)
-    with torch.cuda.stream(s):
-        _REF_STREAM.clear()
-        hot_path_step(layers, B, N, False, True)     # side stream + per-stream workspaces exist before the capture
-        torch.cuda.synchronize()
-        with torch.cuda.graph(g, stream=s):
-            gouts = hot_path_step(layers, B, N, False, True)
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
+    cap = CapturedStep(layers, B, N)
     for _ in range(2):
-        g.replay()
-    sec = _time_steps(g.replay, steps)
+        cap.replay()
+    sec = _time_steps(cap.replay, steps)
     ref = hot_path_step(layers, B, N, False, True)
     torch.cuda.synchronize()
-    same = all(torch.equal(a, b) for a, b in zip(ref, gouts))
-    _REF_STREAM.clear()
-    _REF_STREAM.update(saved)
+    same = all(torch.equal(a, b) for a, b in zip(ref, cap.outs))
     return sec, same
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IR_ABI_VERSION 4
+#define IR_ABI_VERSION 5
 #define IR_HEAD_DIM 64
 
 typedef enum ir_status {
@@ -273,16 +273,20 @@ int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32
                             float scale, void* stream);
 
 /*
- * ir_linear_fwd - y = x W^T (+ bias) for the q/k/v (fused, N = 3C) and out projections of the
- * 64x64-token layer class.
+ * ir_linear_fwd - y = x W^T (+ bias): the q/k/v (fused, N = 3C) and out projections of every layer class
+ * (SURVEY.md section 8f rank 4).
  *
- * Replaces attn.to_q/to_k/to_v and attn.to_out[0] (nn.Linear; attn_processors.py:222-230,267) for
- * in_features K in {64, 128, ..., 320}: X-stationary MFMA kernel, W streamed through LDS, fp32
- * accumulation, one rounding to the 16-bit dtype (bias added in fp32 before it); and for K = 640 (the
- * 32x32-token layer class) the same with the contraction split over two waves whose fp32 partial tiles
- * meet in LDS.  Other K return IR_ERR_UNSUPPORTED and the caller keeps the vendor GEMM.
+ * Replaces attn.to_q/to_k/to_v and attn.to_out[0] (nn.Linear; attn_processors.py:222-230,267).  Two kernel families,
+ * both fp32 accumulation with ONE rounding to the 16-bit dtype (bias added in fp32 before it), both deterministic
+ * (no atomics, no split-K reduction through memory):
+ *   - X-stationary (K in {64, 128, ..., 320}, and K = 640 with the contraction split over two waves whose fp32
+ *     partial tiles meet in LDS): X is read once and kept in registers, W streams through LDS; N % 32 == 0,
+ *     N <= 4096 with bias.  Chosen for large M (M * N >= 2^24; 2^25 at K = 640).
+ *   - LDS-tiled (any K % 64 == 0, N % 64 == 0): 256x256 ... 64x128 tiles of Y, both operands through swizzled LDS
+ *     stages; K = 1280 and the small-M shapes of every class.
+ * Other shapes return IR_ERR_UNSUPPORTED.
  *   x (M, K) rows x_ld elements apart; w (N, K) rows w_ld apart (torch Linear weight layout);
- *   bias (N) or NULL; y (M, N) rows y_ld apart; N % 32 == 0; all ld % 8 == 0, pointers 16-B aligned
+ *   bias (N) or NULL; y (M, N) rows y_ld apart; all ld % 8 == 0, pointers 16-B aligned
  */
 int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                   int64_t w_ld, const void* bias, void* y, int64_t y_ld, void* stream);
@@ -294,6 +298,16 @@ int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x,
 int ir_linear_fwd_scaled(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                          int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
                          void* stream);
+/* The same with the kernel named by the caller (benchmarks, A/B, tests of every tile shape): */
+#define IR_LIN_AUTO 0           /* what ir_linear_fwd / ir_linear_fwd_scaled pick (ir_linear_kernel_for) */
+#define IR_LIN_X_STATIONARY 1
+#define IR_LIN_TILED_FIRST 2    /* 2: 256x128, 3: 128x128, 4: 128x64, 5: 256x64, 6: 64x128, 7: 128x256, 8: 256x256 (rows x columns of Y per
+                                   workgroup; the last two with 64 x 128 per wave) */
+int ir_linear_fwd_ex(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                     int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
+                     int32_t kernel, void* stream);
+/* kernel id (IR_LIN_*) the automatic choice makes for a shape, or -1 when no kernel covers it */
+int ir_linear_kernel_for(int64_t m, int32_t n, int32_t k, int32_t has_bias);
 
 /* library identity / diagnostics */
 int ir_abi_version(void);                  /* == IR_ABI_VERSION */

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # IR_LIB_PATH: load an alternative build of the same ABI (compiler-flag A/B experiments)
 LIB_PATH = os.environ.get("IR_LIB_PATH") or os.path.join(_HERE, "libinstantrestore_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 IR_DTYPE_F16, IR_DTYPE_BF16 = 0, 1
 IR_FLAG_INCLUDE_SELF, IR_FLAG_Q_PRESCALED, IR_FLAG_OUT_F32 = 1, 2, 4
@@ -67,6 +67,8 @@ SYMBOLS = {
     "ir_freeu_fourier_filter": (C.c_int, [i32, i64, i32, i32, vp, i64, vp, i64, i32, f32, vp]),
     "ir_linear_fwd": (C.c_int, [i32, i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, vp]),
     "ir_linear_fwd_scaled": (C.c_int, [i32, i32, i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, i32, f32, vp]),
+    "ir_linear_fwd_ex": (C.c_int, [i32, i32, i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, i32, f32, i32, vp]),
+    "ir_linear_kernel_for": (C.c_int, [i64, i32, i32, i32]),
     "ir_zero_invalid_refs": (C.c_int, [i32, i32, i32, i32, vp, vp, i64, i64, i64, i64,
                                        vp, i64, i64, i64, i64, vp]),
 }

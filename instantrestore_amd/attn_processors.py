@@ -101,20 +101,15 @@ def _autocast_or(weight: torch.Tensor, x: torch.Tensor) -> torch.dtype:
     return weight.dtype
 
 
-_SKINNY_MIN_WORK = 1 << 24   # rows * out_features below which the vendor GEMM is as fast (tools/gpu_gemm_probe.py)
-
-
 def _own_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
-    rows = x.numel() // x.shape[-1]
-    return bool(rows * w.shape[0] >= _SKINNY_MIN_WORK and _ops.linear_supported(x, w, bias))
+    """every projection shape of the SD-Turbo topology (K % 64 == 0, N % 64 == 0) runs this library's GEMMs
+    (``ir_linear_fwd``: X-stationary kernels for large M at K <= 320 / K = 640, the LDS-tiled kernel for K = 1280 and
+    the small-M shapes); anything else stays ``F.linear``"""
+    return bool(_ops.linear_supported(x, w, bias))
 
 
 def _linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """``F.linear`` with the large K <= 320 and K = 640 shapes (64x64- and 32x32-token layer classes) routed
-    to the X-stationary HIP GEMM (``ir_linear_fwd``, 1.5-1.6x the vendor kernel there); every other shape is a
-    plain library GEMM and stays one."""
-    rows = x.numel() // x.shape[-1]
-    if rows * w.shape[0] >= _SKINNY_MIN_WORK and _ops.linear_supported(x, w, bias):
+    if _ops.linear_supported(x, w, bias):
         return _ops.linear(x, w, bias)
     return torch.nn.functional.linear(x, w, bias)
 
@@ -157,7 +152,7 @@ def _project_qkv(attn, st: _Prepared):
     own = _own_gemm(x, w, None)      # fp32 activations go straight in: the own GEMM casts them while loading
     if x.dtype != dtype and not (own and FUSED_CAST):
         x = x.to(dtype)
-    presc = bool(PRESCALE_Q and c % 32 == 0 and own)
+    presc = bool(PRESCALE_Q and c % 32 == 0 and own and _ops.tuning_supports_prescaled_q())
     qkv = _ops.linear(x, w, None, scale_cols=c, col_scale=float(attn.scale) * LOG2E) if presc else _linear(x, w, None)
     return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], presc
 

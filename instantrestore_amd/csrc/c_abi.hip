@@ -356,24 +356,56 @@ int ir_linear_fwd(int32_t dtype, int64_t m, int32_t n, int32_t k, const void* x,
 int ir_linear_fwd_scaled(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                          int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
                          void* stream) {
+  return ir_linear_fwd_ex(dtype, x_is_f32, m, n, k, x, x_ld, w, w_ld, bias, y, y_ld, scale_cols, col_scale, IR_LIN_AUTO, stream);
+}
+
+static bool x_stationary_covers(int32_t n, int32_t k, const void* bias) {
+  return ((k % 64 == 0 && k <= 320) || k == 640) && n % 32 == 0 && (bias == nullptr || n <= kLinearMaxBiasN);
+}
+
+int ir_linear_kernel_for(int64_t m, int32_t n, int32_t k, int32_t has_bias) {
+  static const int dummy = 0;
+  const bool xs = x_stationary_covers(n, k, has_bias ? (const void*)&dummy : nullptr);
+  const bool tiled = (k % 64 == 0) && (n % 64 == 0);
+  if (!xs && !tiled) return -1;
+  if (!tiled) return IR_LIN_X_STATIONARY;
+  // the X-stationary kernels read X once (and cast fp32 activations once) and win where that is the traffic that
+  // matters: large M.  Thresholds from profiles/r3_gemm_probe.txt: K <= 320 from 2^24 output elements (32768 x 960 yes,
+  // 32768 x 320 no), K = 640 from 2^25 (32768 x 1920 yes, 32768 x 640 no)
+  if (xs && m * (int64_t)n >= (k == 640 ? (1LL << 25) : (1LL << 24))) return IR_LIN_X_STATIONARY;
+  return IR_LIN_TILED_FIRST + ir_linear_tiled_pick(m, n);
+}
+
+int ir_linear_fwd_ex(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                     int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
+                     int32_t kernel, void* stream) {
   if (scale_cols < 0 || scale_cols > n || (scale_cols % 32) != 0) return fail(IR_ERR_INVALID_ARG, "scale_cols %d: a multiple of 32 in [0, N]", scale_cols);
   if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d: fp16 (0) / bf16 (1)", dtype);
   if (!x || !w || !y) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
   if (m <= 0 || n <= 0 || k <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
-  if ((k % 64 != 0 || k > 320) && k != 640) return fail(IR_ERR_UNSUPPORTED, "K = %d: this kernel covers K in {64,...,320} and 640", k);
-  if (n % 32 != 0) return fail(IR_ERR_UNSUPPORTED, "N = %d must be a multiple of 32", n);
-  if (bias != nullptr && n > kLinearMaxBiasN) return fail(IR_ERR_UNSUPPORTED, "N = %d with bias: at most %d", n, kLinearMaxBiasN);
+  if (kernel == IR_LIN_AUTO) kernel = ir_linear_kernel_for(m, n, k, bias != nullptr);
+  if (kernel < 0) return fail(IR_ERR_UNSUPPORTED, "K = %d, N = %d: K must be a multiple of 64 and N of 64 (of 32 for K <= 320 or K = 640)", k, n);
+  if (kernel == IR_LIN_X_STATIONARY) {
+    if (!x_stationary_covers(n, k, bias))
+      return fail(IR_ERR_UNSUPPORTED, "X-stationary kernel: K in {64,...,320} or 640, N %% 32 == 0, N <= %d with bias (K = %d, N = %d)", kLinearMaxBiasN, k, n);
+  } else if (kernel < IR_LIN_TILED_FIRST || kernel >= IR_LIN_TILED_FIRST + IR_LIN_TILE_COUNT) {
+    return fail(IR_ERR_INVALID_ARG, "kernel %d: 0 auto, 1 X-stationary, %d..%d tiled", kernel, IR_LIN_TILED_FIRST, IR_LIN_TILED_FIRST + IR_LIN_TILE_COUNT - 1);
+  } else if (k % 64 != 0 || !ir_linear_tiled_cfg_ok(kernel - IR_LIN_TILED_FIRST, n)) {
+    return fail(IR_ERR_UNSUPPORTED, "tiled kernel %d: K %% 64 == 0 and N a multiple of the tile width (K = %d, N = %d)", kernel, k, n);
+  }
   if (m > 0x7fffffffLL - 256) return fail(IR_ERR_UNSUPPORTED, "M too large");
   if (x_ld < k || w_ld < k || y_ld < n || (x_ld % 8) || (w_ld % 8) || (y_ld % 8))
     return fail(IR_ERR_UNSUPPORTED, "leading dimensions must cover a row and be multiples of 8 elements");
   if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (bias != nullptr && !aligned16(bias)))
     return fail(IR_ERR_UNSUPPORTED, "pointers must be 16-byte aligned");
   if ((int64_t)n * w_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "weight larger than 2 GiB");
+  if (256 * x_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "x_ld too large");
   LinearKParams p;
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.x_ld = x_ld; p.w_ld = w_ld; p.y_ld = y_ld;
   p.M = (int32_t)m; p.N = n; p.K = k; p.nsplit = 1;
   p.scale_cols = scale_cols; p.col_scale = col_scale; p.x_f32 = x_is_f32 ? 1 : 0;
-  const hipError_t e = ir_launch_linear_skinny(p, dtype, (hipStream_t)stream);
+  const hipError_t e = kernel == IR_LIN_X_STATIONARY ? ir_launch_linear_skinny(p, dtype, (hipStream_t)stream)
+                                                     : ir_launch_linear_tiled(p, dtype, kernel - IR_LIN_TILED_FIRST, (hipStream_t)stream);
   if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "linear launch: %s", hipGetErrorString(e));
   return IR_OK;
 }

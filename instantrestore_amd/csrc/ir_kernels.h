@@ -158,4 +158,19 @@ struct LinearKParams {
   float col_scale;      // (scale_cols % 32 == 0; 0 = none): the softmax scale * log2(e) on the q third of a fused q/k/v
 };
 hipError_t ir_launch_linear_skinny(const LinearKParams& p, int dtype, hipStream_t s);
+
+// ---- linear_tiled.hip: LDS-tiled Y = X W^T (+ bias) for any K % 64 == 0, N % 64 == 0 (K = 1280, small-M shapes) ----
+enum {   // tile shapes (rows x columns of Y per workgroup); values are the `kernel` argument of ir_linear_fwd_ex minus 2
+  IR_LIN_TILE_256x128 = 0,   // 8 waves
+  IR_LIN_TILE_128x128 = 1,   // 4 waves
+  IR_LIN_TILE_128x64 = 2,    // 2 waves
+  IR_LIN_TILE_256x64 = 3,    // 4 waves
+  IR_LIN_TILE_64x128 = 4,    // 2 waves
+  IR_LIN_TILE_128x256 = 5,   // 4 waves, 64 x 128 per wave
+  IR_LIN_TILE_256x256 = 6,   // 8 waves, 64 x 128 per wave
+  IR_LIN_TILE_COUNT = 7
+};
+hipError_t ir_launch_linear_tiled(const LinearKParams& p, int dtype, int cfg, hipStream_t s);
+int ir_linear_tiled_pick(int64_t M, int N);
+bool ir_linear_tiled_cfg_ok(int cfg, int N);
 void ir_host_lanczos_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk);

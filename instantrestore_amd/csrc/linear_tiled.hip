@@ -1,0 +1,314 @@
+// linear_tiled.hip - Y[M,N] = X[M,K] W[N,K]^T (+ bias) for every projection shape the X-stationary kernels of
+// linear_skinny.hip do not cover: K = 1280 (the 16x16-token layer class: to_q/k/v fused N = 3840, to_out N = 1280), and
+// the small-M shapes of every class (8 identities: M = 2048 / 8192 / 32768 rows), gfx950.  Round 3: these were the
+// last vendor GEMMs of the step (attn_processors.py:222-230,267).
+//
+// Shape of the kernel: a workgroup owns a BM x BN tile of Y and walks K in 64-wide steps; both operand tiles live in LDS
+// as 128-byte rows whose 16-byte slots are XOR-swizzled with (row >> 1) & 7 (the attention kernels' K-tile image:
+// conflict-free ds_read_b128 of the MFMA fragments), two stages.  16-bit operands arrive by LDS-DMA (buffer_load ... lds
+// issued from asm, the swizzle applied to the SOURCE slot a lane fetches; ragged row tails are zero-filled by the
+// descriptor's bounds check).  fp32 activations (the LayerNorm output under autocast, inference/test.py:83) cannot ride
+// the DMA - it moves bytes - so they are loaded to registers one K-step ahead, rounded (RNE: the bytes `.to(dtype)` would
+// produce) after the step's MFMAs and written with ds_write_b128: the cast costs no pass over memory.
+// Products are issued "swapped" (Y^T = W X^T) on v_mfma_f32_32x32x16 like everywhere in this library: a lane owns one
+// row of Y and 16 of its columns per 32x32 block, so the epilogue (column scale of the pre-scaled-Q contract, bias,
+// ONE rounding) stages 64 x 64 per wave in LDS and leaves as whole 128-byte lines of Y.
+// Tile -> workgroup map: every XCD owns a contiguous range of tiles (its L2 sees each operand panel once), and inside
+// it tiles are ordered 8 row panels x all column tiles, so the ~64 tiles resident on an XCD at a time form an 8 x 8
+// patch that shares its X and W panels in that L2.
+// Deterministic: no atomics, no split-K; the accumulation order of an output element is fixed by the tile shape.
+#include <type_traits>
+
+#include "ir_common.h"
+#include "ir_kernels.h"
+
+namespace {
+
+constexpr int kTiledPitch = 144;   // staging tile row: 128 B (64 columns of Y) + 16 B pad
+
+template <typename T, int WM, int WN, int MI, int NI, bool XF32, bool ILV>
+__global__ void __launch_bounds__(WM * WN * 64, 2) linear_tiled_kernel(const LinearKParams p) {
+  using Tr = ElemTraits<T>;
+  using v8 = typename Tr::v8;
+  using v4 = typename Tr::v4;
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  constexpr int XT = BM * 128, WT = BN * 128, STAGE = XT + WT;
+  constexpr int XP = BM / 8 / NW, WP = BN / 8 / NW;    // 1-KiB LDS-DMA pieces per wave and K-step
+  constexpr int XU = BM * 8 / NT;                      // fp32 path: 8-element units per thread and K-step
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide over the waves");
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm_tiled[];
+  unsigned char* const smem = dsm_tiled;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid - wm * WN;
+  const int hi = lane >> 5, lq = lane & 31;
+
+  // ---- tile decode -----------------------------------------------------------------------------------------------
+  const int MT = (p.M + BM - 1) / BM, NTl = p.N / BN;
+  const int logical = xcd_remap((int)blockIdx.x, MT * NTl);
+  constexpr int GM = 8;
+  const int grp = logical / (GM * NTl), rem = logical - grp * (GM * NTl);
+  const int gm = (MT - grp * GM) < GM ? (MT - grp * GM) : GM;
+  const int tm = grp * GM + rem % gm, tn = rem / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
+  const int KT = p.K >> 6;
+
+  // ---- operand streams ---------------------------------------------------------------------------------------------
+  const T* const wbase = (const T*)p.w + (int64_t)n0 * p.w_ld;
+  const i32x4 wrs = make_rsrc_words(wbase, (unsigned)(((int64_t)(BN - 1) * p.w_ld + p.K) * 2));
+  unsigned wvo[WP];
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    const int row = 8 * (wid + j * NW) + (lane >> 3);
+    wvo[j] = (unsigned)(row * p.w_ld * 2 + ((((lane & 7) ^ ((row >> 1) & 7))) << 4));
+  }
+  i32x4 xrs = wrs;
+  unsigned xvo[XF32 ? 1 : XP];
+  const float* xfp[XF32 ? XU : 1];
+  int xlds[XF32 ? XU : 1];
+  if constexpr (!XF32) {
+    const T* const xbase = (const T*)p.x + (int64_t)m0 * p.x_ld;
+    xrs = make_rsrc_words(xbase, (unsigned)(((int64_t)(rows_valid - 1) * p.x_ld + p.K) * 2));
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int row = 8 * (wid + j * NW) + (lane >> 3);
+      xvo[j] = (unsigned)(row * p.x_ld * 2 + ((((lane & 7) ^ ((row >> 1) & 7))) << 4));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+      const int u = tid + j * NT, row = u >> 3, ch = u & 7;
+      const int gr = (m0 + row) < p.M ? (m0 + row) : (p.M - 1);   // rows past M: copies of the last row (never stored)
+      xfp[j] = (const float*)p.x + (int64_t)gr * p.x_ld + ch * 8;
+      xlds[j] = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+    }
+  }
+  // one 1-KiB piece of the next stage: pieces [0, WP) are W's, [WP, WP + XP) X's (16-bit activations only)
+  constexpr int NPIECE = WP + (XF32 ? 0 : XP);
+  auto issue_piece = [&](int j, int kt, int slot) {
+    unsigned char* const sx = smem + slot * STAGE;
+    if (j < WP) buffer_load_lds16_async(wrs, sx + XT + (wid + j * NW) * 1024, wvo[j] + kt * 128);
+    else if constexpr (!XF32) buffer_load_lds16_async(xrs, sx + (wid + (j - WP) * NW) * 1024, xvo[j - WP] + kt * 128);
+  };
+  auto issue_dma = [&](int kt, int slot) {
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) issue_piece(j, kt, slot);
+  };
+  // fp32 activations, one K-step ahead in registers.  The loads are issued from asm: hipcc sinks a plain load to its
+  // first use - BEHIND the step's MFMAs, where it is waited for at once (measured: 1.5x the 16-bit path) - and waits
+  // for a volatile one immediately.  An asm load is invisible to hipcc's waitcnt bookkeeping, so the statement that
+  // waits for them names every destination register as read-write: no consumer can be scheduled above it.
+  f32x4 xr[XF32 ? XU : 1][2];
+  auto load_x32 = [&](int kt) {
+    if constexpr (XF32) {
+#pragma unroll
+      for (int j = 0; j < XU; ++j) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[j][0]) : "v"(xfp[j] + kt * 64) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(xr[j][1]) : "v"(xfp[j] + kt * 64) : "memory");
+      }
+    }
+  };
+  auto put_x32 = [&](int slot) {
+    if constexpr (XF32) {
+      unsigned char* const sx = smem + slot * STAGE;
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0][0]), "+v"(xr[0][1]) : : "memory");
+#pragma unroll
+      for (int j = 1; j < XU; ++j) asm volatile("" : "+v"(xr[j][0]), "+v"(xr[j][1]));
+#pragma unroll
+      for (int j = 0; j < XU; ++j) {
+        const f32x8 f = __builtin_shufflevector(xr[j][0], xr[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        *(IR_LDS v8*)(IR_LDS unsigned char*)(sx + xlds[j]) = __builtin_convertvector(f, v8);
+      }
+    }
+  };
+
+  // ---- fragment addresses ------------------------------------------------------------------------------------------
+  int fread[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) fread[ks] = lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4);
+  const int xrow0 = wm * (MI * 32) * 128, wrow0 = XT + wn * (NI * 32) * 128;
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // The MFMAs of one K-step.  `dma_kt >= 0`: the LDS-DMA pieces of stage dma_kt are issued BETWEEN the MFMAs of the
+  // first two k-substeps, one piece per `STRIDE` MFMAs.  Issued in a bunch at the top of the step they cost each wave
+  // ~100 issue cycles apiece with the matrix pipe idle - both waves of a SIMD leave the barrier in the same phase -
+  // (measured: the 256x256 tile ran at ~50 % matrix-pipe occupancy); between MFMAs they ride in the shadow of the
+  // 32-cycle matrix instructions, and issuing them in the first half leaves the second half for them to land.
+  constexpr int HALF_MFMA = 2 * MI * NI;
+  constexpr int STRIDE = (HALF_MFMA / NPIECE) > 0 ? (HALF_MFMA / NPIECE) : 1;
+  auto compute = [&](int slot, int dma_kt, int dma_slot) {
+    const unsigned char* const st = smem + slot * STAGE;
+    v8 wf[2][NI], xf[2][MI];
+    auto rd = [&](int ks, int b) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[b][ni] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(st + wrow0 + ni * 4096 + fread[ks]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[b][mi] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(st + xrow0 + mi * 4096 + fread[ks]);
+    };
+    rd(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) rd(ks + 1, (ks + 1) & 1);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          acc[mi][ni] = Tr::mfma(wf[ks & 1][ni], xf[ks & 1][mi], acc[mi][ni]);
+          if constexpr (ILV) {
+            const int m = ks * MI * NI + mi * NI + ni;           // MFMA index within the step (compile-time after unrolling)
+            if (m < HALF_MFMA && (m % STRIDE) == STRIDE - 1 && (m / STRIDE) < NPIECE) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (dma_kt >= 0) issue_piece(m / STRIDE, dma_kt, dma_slot);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            if (m == HALF_MFMA - 1) {                            // pieces that did not fit a slot of their own
+#pragma unroll
+              for (int j = HALF_MFMA / STRIDE; j < NPIECE; ++j)
+                if (dma_kt >= 0) issue_piece(j, dma_kt, dma_slot);
+            }
+          }
+        }
+    }
+  };
+
+  // ---- main loop: stage kt+1 while kt is multiplied --------------------------------------------------------------
+  issue_dma(0, 0);
+  load_x32(0);
+  put_x32(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt + 1 < KT; ++kt) {
+    const int cur = kt & 1;
+    if constexpr (!ILV) issue_dma(kt + 1, cur ^ 1);   // that stage was last read in step kt-1, behind the barrier that ended it
+    load_x32(kt + 1);
+    compute(cur, kt + 1, cur ^ 1);
+    put_x32(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  compute((KT - 1) & 1, -1, 0);
+  __syncthreads();                  // every wave is done with the operand stages: they become the output staging tiles
+
+  // ---- epilogue: column scale, bias, one rounding, transposed through LDS into whole lines of Y -------------------
+  // (64 columns at a time: a wave's LDS operations execute in order, so the tile is reused without a barrier)
+  unsigned char* const tb = smem + wid * (MI * 32 * kTiledPitch);
+  const int row_base = m0 + wm * (MI * 32);
+  v4 bvs[NI][4];   // the lane's 16 bias values per 32-column block, fetched together ahead of the loops
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bvs[ni][g] = *(const v4*)((const T*)p.bias + n0 + wn * (NI * 32) + ni * 32 + 8 * g + 4 * hi);
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bvs[ni][g] = v4{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int nh = 0; nh < NI / 2; ++nh) {
+    const int ncol0 = n0 + wn * (NI * 32) + nh * 64;
+#pragma unroll
+    for (int n2 = 0; n2 < 2; ++n2) {
+      const int ni = 2 * nh + n2;
+      const float cs = (ncol0 + n2 * 32) < p.scale_cols ? p.col_scale : 1.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 bz;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bz[i] = (float)bvs[ni][g][i];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          f32x4 f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) f[i] = acc[mi][ni][4 * g + i] * cs + bz[i];
+          *(v4*)(tb + (mi * 32 + lq) * kTiledPitch + n2 * 64 + (8 * g + 4 * hi) * 2) = __builtin_convertvector(f, v4);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < MI * 4; ++j) {
+      const int r = 8 * j + (lane >> 3);
+      const u32x4 v = *(const u32x4*)(tb + r * kTiledPitch + (lane & 7) * 16);
+      const int row = row_base + r;
+      if (row < p.M) *(u32x4*)((T*)p.y + (int64_t)row * p.y_ld + ncol0 + (lane & 7) * 8) = v;
+    }
+  }
+}
+
+template <typename T, int WM, int WN, int MI, int NI, bool XF32, bool ILV>
+hipError_t launch_cfg(const LinearKParams& p, hipStream_t s) {
+  constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+  constexpr size_t stage = (size_t)(BM + BN) * 128;
+  constexpr size_t epi = (size_t)WM * WN * MI * 32 * kTiledPitch;
+  constexpr size_t dyn = 2 * stage > epi ? 2 * stage : epi;
+  static bool attr_set[64] = {};   // per instantiation and per device; idempotent
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
+  if (!attr_set[dev]) {
+    hipError_t ea = hipFuncSetAttribute((const void*)linear_tiled_kernel<T, WM, WN, MI, NI, XF32, ILV>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (ea != hipSuccess) return ea;
+    attr_set[dev] = true;
+  }
+  const int MT = (p.M + BM - 1) / BM, NTl = p.N / BN;
+  hipLaunchKernelGGL((linear_tiled_kernel<T, WM, WN, MI, NI, XF32, ILV>), dim3((unsigned)(MT * NTl)), dim3(WM * WN * 64), dyn, s, p);
+  return hipGetLastError();
+}
+
+template <typename T, bool XF32>
+hipError_t launch_x(const LinearKParams& p, int cfg, hipStream_t s) {
+#ifdef LIN_TILED_NO_ILV   // A/B build: every LDS-DMA piece of a step issued at its top
+  constexpr bool I = false;
+#else
+  constexpr bool I = true;
+#endif
+  switch (cfg) {
+    case IR_LIN_TILE_256x128: return launch_cfg<T, 4, 2, 2, 2, XF32, I>(p, s);
+    case IR_LIN_TILE_128x128: return launch_cfg<T, 2, 2, 2, 2, XF32, I>(p, s);
+    case IR_LIN_TILE_128x64: return launch_cfg<T, 2, 1, 2, 2, XF32, I>(p, s);
+    case IR_LIN_TILE_256x64: return launch_cfg<T, 4, 1, 2, 2, XF32, I>(p, s);
+    case IR_LIN_TILE_64x128: return launch_cfg<T, 1, 2, 2, 2, XF32, I>(p, s);
+    case IR_LIN_TILE_128x256: return launch_cfg<T, 2, 2, 2, 4, XF32, I>(p, s);
+    case IR_LIN_TILE_256x256: return launch_cfg<T, 4, 2, 2, 4, XF32, I>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+}  // namespace
+
+// tile shape for a problem, from the measurements of tools/gpu_gemm_probe3.py (profiles/r3_gemm_probe.txt): the 256x256
+// tile (64 x 128 per wave: 0.75 LDS fragment reads per MFMA, half the L2 traffic per flop of 128x128) wins as soon as
+// its grid covers ~160 of the 256 CUs; below that 128x128 at two workgroups per CU, and 64-row tiles when even that
+// grid leaves CUs idle
+int ir_linear_tiled_pick(int64_t M, int N) {
+  auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (int64_t)(N / bn); };
+  if (N % 256 == 0 && tiles(256, 256) >= 160) return IR_LIN_TILE_256x256;
+  if (N % 128 == 0) return tiles(128, 128) >= 128 ? IR_LIN_TILE_128x128 : IR_LIN_TILE_64x128;
+  return tiles(256, 64) >= 512 ? IR_LIN_TILE_256x64 : IR_LIN_TILE_128x64;
+}
+
+bool ir_linear_tiled_cfg_ok(int cfg, int N) {
+  switch (cfg) {
+    case IR_LIN_TILE_256x128: case IR_LIN_TILE_128x128: case IR_LIN_TILE_64x128: return N % 128 == 0;
+    case IR_LIN_TILE_128x64: case IR_LIN_TILE_256x64: return N % 64 == 0;
+    case IR_LIN_TILE_128x256: case IR_LIN_TILE_256x256: return N % 256 == 0;
+    default: return false;
+  }
+}
+
+hipError_t ir_launch_linear_tiled(const LinearKParams& p, int dtype, int cfg, hipStream_t s) {
+  if (dtype == 1) return p.x_f32 ? launch_x<__bf16, true>(p, cfg, s) : launch_x<__bf16, false>(p, cfg, s);
+  return p.x_f32 ? launch_x<_Float16, true>(p, cfg, s) : launch_x<_Float16, false>(p, cfg, s);
+}

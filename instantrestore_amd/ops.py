@@ -355,26 +355,34 @@ def tensor2im_u8(x: torch.Tensor) -> torch.Tensor:
     return out[0] if squeeze else out
 
 
-LINEAR_MAX_K = 320   # ir_linear_fwd: in_features in {64, ..., 320} and 640; everything else is the vendor GEMM's
-LINEAR_SPLIT_K = (640,)
+LIN_AUTO, LIN_X_STATIONARY, LIN_TILED_FIRST = 0, 1, 2   # IR_LIN_* of include/instantrestore_hip.h
+LIN_KERNELS = {"auto": 0, "x_stationary": 1, "256x128": 2, "128x128": 3, "128x64": 4, "256x64": 5, "64x128": 6, "128x256": 7, "256x256": 8}
 
 
 def linear_supported(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:
-    """shapes / layouts ``ir_linear_fwd`` implements (the caller keeps ``F.linear`` otherwise)"""
+    """shapes / layouts ``ir_linear_fwd`` implements: K % 64 == 0 and N % 64 == 0 (LDS-tiled kernel), or K <= 320 / K = 640
+    with N % 32 == 0 (X-stationary kernels)"""
     n, k = weight.shape
-    return (x.is_cuda and weight.dtype in _DT and (x.dtype == weight.dtype or x.dtype == torch.float32) and x.shape[-1] == k
-            and ((k % 64 == 0 and k <= LINEAR_MAX_K) or k in LINEAR_SPLIT_K) and n % 32 == 0 and weight.stride(1) == 1 and weight.stride(0) % 8 == 0
-            and (bias is None or (bias.dtype == weight.dtype and bias.is_contiguous() and n <= 4096))
-            and x.numel() > 0)
+    if not (x.is_cuda and weight.dtype in _DT and (x.dtype == weight.dtype or x.dtype == torch.float32) and x.shape[-1] == k
+            and weight.stride(1) == 1 and weight.stride(0) % 8 == 0 and x.numel() > 0
+            and (bias is None or (bias.dtype == weight.dtype and bias.is_contiguous()))):
+        return False
+    rows = x.numel() // k
+    return _lib.lib().ir_linear_kernel_for(rows, n, k, 0 if bias is None else 1) >= 0
+
+
+def linear_kernel_for(rows: int, n: int, k: int, bias: bool) -> int:
+    """IR_LIN_* id of the kernel the automatic choice launches for a shape (-1: unsupported)"""
+    return int(_lib.lib().ir_linear_kernel_for(int(rows), int(n), int(k), 1 if bias else 0))
 
 
 @_on_tensor_device
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, scale_cols: int = 0,
-           col_scale: float = 1.0) -> torch.Tensor:
-    """``F.linear(x, weight, bias)`` for 16-bit ``x (..., K)``, ``weight (N, K)`` with K <= 320 or K = 640
-    (``ir_linear_fwd``): fp32 accumulation, one rounding.  Raises for unsupported shapes.  ``scale_cols`` / ``col_scale``:
-    the first ``scale_cols`` output columns are multiplied by ``col_scale`` in fp32 before that rounding.  ``x`` may be
-    fp32 (with 16-bit ``weight``): it is rounded to the weight's dtype while loaded (the autocast cast, fused)."""
+           col_scale: float = 1.0, kernel: int = 0) -> torch.Tensor:
+    """``F.linear(x, weight, bias)`` for ``x (..., K)``, 16-bit ``weight (N, K)`` (``ir_linear_fwd_ex``): fp32 accumulation,
+    one rounding.  Raises for unsupported shapes.  ``scale_cols`` / ``col_scale``: the first ``scale_cols`` output columns
+    are multiplied by ``col_scale`` in fp32 before that rounding.  ``x`` may be fp32: it is rounded to the weight's dtype
+    while loaded (the autocast cast, fused).  ``kernel``: ``LIN_KERNELS`` (0 = the library's own choice)."""
     _need_gpu(x, weight, bias)
     _forward_only(x, weight, bias)
     n, k = weight.shape
@@ -382,10 +390,10 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
         x2 = x2.contiguous()
     y = torch.empty((x2.shape[0], n), dtype=weight.dtype, device=x.device)
-    rc = _lib.lib().ir_linear_fwd_scaled(_dtype_code(weight), 1 if x.dtype == torch.float32 else 0, x2.shape[0], n, k, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
-                                         weight.stride(0), None if bias is None else bias.data_ptr(), y.data_ptr(), n,
-                                         int(scale_cols), float(col_scale), _stream())
-    _lib.check(rc, "ir_linear_fwd_scaled")
+    rc = _lib.lib().ir_linear_fwd_ex(_dtype_code(weight), 1 if x.dtype == torch.float32 else 0, x2.shape[0], n, k, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
+                                     weight.stride(0), None if bias is None else bias.data_ptr(), y.data_ptr(), n,
+                                     int(scale_cols), float(col_scale), int(kernel), _stream())
+    _lib.check(rc, "ir_linear_fwd_ex")
     return y.view(*x.shape[:-1], n)
 
 
@@ -444,6 +452,12 @@ def preprocess_lanczos(descs, size: int, dtype: torch.dtype, device: torch.devic
 
 
 _TUNING = int(os.environ.get("IR_ATTN_VARIANT", "0") or 0)
+
+
+def tuning_supports_prescaled_q() -> bool:
+    """``IR_FLAG_Q_PRESCALED`` is implemented by the default dispatch and by the kernels it picks from (tuning 0, 11, 13,
+    17); under any other A/B ``tuning`` the processors keep the plain q (the C ABI rejects the combination)"""
+    return _TUNING in (0, 11, 13, 17)
 
 
 def set_attn_variant(variant: int) -> int:

@@ -59,13 +59,86 @@ def test_linear_exact_column_order_and_strided_input():
     assert torch.equal(y6.float(), (x6.float() @ w6.float().T + b.float()).to(torch.bfloat16).float())
 
 
+TILED = ["256x128", "128x128", "128x64", "256x64", "64x128", "128x256", "256x256"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("kernel", TILED)
+@pytest.mark.parametrize("M,N,K,bias", [
+    (256, 128, 64, False), (300, 256, 128, True), (2048, 1280, 1280, True), (2048, 3840, 1280, False),
+    (8192, 1280, 1280, True), (1, 128, 1280, True), (257, 384, 1280, False), (8192, 640, 640, True), (4099, 1920, 640, False),
+    (32768, 320, 320, True), (129, 64, 320, True),
+])
+def test_tiled_linear_matches_float64(dtype, kernel, M, N, K, bias):
+    """the LDS-tiled kernel (round 3: K = 1280 and the small-M shapes, every tile shape) against a float64 product of the
+    same 16-bit inputs; with fp32 activations the result must be the SAME BITS as with the pre-cast ones (the fused cast is
+    `.to(dtype)`)"""
+    from instantrestore_amd import ops
+    if N % int(kernel.split("x")[1]) != 0:
+        pytest.skip("tile width does not divide N")
+    kid = ops.LIN_KERNELS[kernel]
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    x32 = torch.randn(M, K, generator=g)
+    x = x32.to(dtype)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    b = torch.randn(N, generator=g).to(dtype) if bias else None
+    bc = None if b is None else b.cuda()
+    y = ops.linear(x.cuda(), w.cuda(), bc, kernel=kid)
+    assert y.shape == (M, N) and y.dtype == dtype
+    ref = x.double().numpy() @ w.double().numpy().T
+    if bias:
+        ref = ref + b.double().numpy()
+    err = np.abs(y.double().cpu().numpy() - ref)
+    bound = TOL[dtype] * np.maximum(1.0, np.abs(ref))
+    assert (err <= bound).all(), (err.max(), np.unravel_index(np.argmax(err - bound), err.shape))
+    y32 = ops.linear(x32.cuda(), w.cuda(), bc, kernel=kid)
+    assert torch.equal(y32, y)
+    # column scale of the pre-scaled-Q contract: columns [0, 64) times 0.18 in fp32 before the one rounding
+    ys = ops.linear(x.cuda(), w.cuda(), bc, kernel=kid, scale_cols=64, col_scale=0.18)
+    refs = ref.copy()
+    refs[:, :64] = (refs[:, :64] - (b.double().numpy()[:64] if bias else 0.0)) * np.float32(0.18) + (b.double().numpy()[:64] if bias else 0.0)
+    errs = np.abs(ys.double().cpu().numpy() - refs)
+    assert (errs <= TOL[dtype] * np.maximum(1.0, np.abs(refs))).all()
+    assert torch.equal(ys[:, 64:], y[:, 64:])
+
+
+@pytest.mark.parametrize("kernel", TILED)
+def test_tiled_linear_exact_layout(kernel):
+    """integer-valued operands make every product exact: a permuted output column / row, a wrong swizzle slot or a stale
+    LDS stage is an exact mismatch.  Ragged M, strided x rows, a row slice of a fused weight."""
+    from instantrestore_amd import ops
+    kid = ops.LIN_KERNELS[kernel]
+    g = torch.Generator().manual_seed(11)
+    xbig = torch.randint(-3, 4, (3, 333, 1280 + 64), generator=g).to(torch.bfloat16).cuda()
+    x = xbig[..., :1280]                       # row stride 1344 elements
+    wbig = torch.randint(-2, 3, (3 * 256, 1280), generator=g).to(torch.bfloat16).cuda()
+    b = torch.randint(-4, 5, (256,), generator=g).to(torch.bfloat16).cuda()
+    y = ops.linear(x, wbig[256:512], b, kernel=kid)
+    ref = (x.float() @ wbig[256:512].float().T + b.float())
+    assert y.shape == (3, 333, 256)
+    assert torch.equal(y.float(), ref.to(torch.bfloat16).float())
+
+
+def test_linear_auto_choice_covers_every_projection_of_the_topology():
+    """no projection of the SD-Turbo attention topology is left to a vendor GEMM"""
+    from instantrestore_amd import ops
+    for sets in (1, 4, 8, 32, 64):
+        for (L, C) in ((256, 1280), (1024, 640), (4096, 320), (16384, 320)):
+            for N, bias in ((3 * C, False), (C, True), (2 * C, False)):
+                assert ops.linear_kernel_for(sets * L, N, C, bias) >= 1, (sets, L, C, N)
+    assert ops.linear_kernel_for(77 * 8, 1280, 1024, False) >= 2      # cross-attention to_k/to_v: text width 1024
+
+
 def test_linear_rejects_what_it_does_not_implement():
     from instantrestore_amd import _lib, ops
-    x = torch.zeros(64, 1280, device="cuda", dtype=torch.bfloat16)
-    w = torch.zeros(64, 1280, device="cuda", dtype=torch.bfloat16)
+    x = torch.zeros(64, 1000, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(64, 1000, device="cuda", dtype=torch.bfloat16)
     assert not ops.linear_supported(x, w, None)
     with pytest.raises(_lib.IRError):
         ops.linear(x, w)
+    x = torch.zeros(64, 1280, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(96, 1280, device="cuda", dtype=torch.bfloat16)      # K = 1280 needs N % 64 == 0
+    assert not ops.linear_supported(x, w, None)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.linear(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(32, 64, dtype=torch.bfloat16))
 

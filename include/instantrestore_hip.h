@@ -123,6 +123,8 @@ typedef struct ir_shared_attn_args {
 #define IR_TUNE_PIPE32_EARLYQK 14
 #define IR_TUNE_SP64 16   /* development builds (-DIR_ABLATIONS) only: the one-wave-per-SIMD experiment */
 #define IR_TUNE_TP32 17   /* development builds (-DIR_ABLATIONS) only: the three-stage 32-row experiment */
+#define IR_TUNE_PIPE32_POSTCHECK 18   /* 32-row kernel, pre-scaled Q, reference checked after the exponentials (needs
+                                         IR_FLAG_Q_PRESCALED; parity-green, same speed as PIPE32_PRESCALE_Q: opt-in) */
 
 /*
  * Scratch for the remainder split: when the number of (batch, head, query-block) work items is not

@@ -65,8 +65,11 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->include_self = inc ? 1 : 0;
   p->q_prescaled = (a->flags & IR_FLAG_Q_PRESCALED) ? 1 : 0;
   p->out_f32 = (a->flags & IR_FLAG_OUT_F32) ? 1 : 0;
-  if (p->q_prescaled && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q && a->tuning != IR_TUNE_TP32)
-    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8 and PIPE32_PRESCALE_Q kernels only");
+  if (p->q_prescaled && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q && a->tuning != IR_TUNE_TP32 &&
+      a->tuning != IR_TUNE_PIPE32_POSTCHECK)
+    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8, PIPE32_PRESCALE_Q and PIPE32_POSTCHECK kernels only");
+  if (!p->q_prescaled && a->tuning == IR_TUNE_PIPE32_POSTCHECK)
+    return fail(IR_ERR_UNSUPPORTED, "IR_TUNE_PIPE32_POSTCHECK needs IR_FLAG_Q_PRESCALED (its scores must already carry the reference)");
   p->tiles_self = inc ? (a->len_self + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->tiles_ref = a->n_refs > 0 ? (a->len_ref + IR_KV_TILE - 1) / IR_KV_TILE : 0;
   p->ntiles = p->tiles_self + a->n_refs * p->tiles_ref;
@@ -97,17 +100,25 @@ const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
   if (build_attn_params(args, &p, false) != IR_OK) return "";
   const int v = args->tuning & 31;
   const bool fold = p.aa != nullptr;
+  const bool w64 = (v == 0 && ir_attn_default_is_w64(p)) || v == 13;
+  if (p.q_prescaled) {   // the dispatch of ir_launch_shared_attn_fwd, restated for reporting
+    if (w64) return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, pre-scaled Q (reference through the MFMA C operand, checked after the exponentials), AdaIN ratio-frame fold>"
+                         : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, pre-scaled Q (reference through the MFMA C operand, checked after the exponentials)>";
+    if (v == 11 || v == 0) return fold ? "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q, AdaIN fold>" : "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q>";
+    if (v == 18) return fold ? "shared_attn_fwd_pipe_kernel<4 waves, pre-scaled Q, reference checked after the exponentials, AdaIN fold>"
+                                       : "shared_attn_fwd_pipe_kernel<4 waves, pre-scaled Q, reference checked after the exponentials>";
+  }
   switch (v) {
-    case 0: if (p.q_prescaled) return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, pre-scaled Q (reference through the MFMA C operand), AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, pre-scaled Q (reference through the MFMA C operand)>")
-                                                             : "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q>";
-            return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>")
+    case 0: return ir_attn_default_is_w64(p) ? (fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>")
                                              : (fold ? "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK, AdaIN fold>" : "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK>");
     case 12: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves>";
     case 13: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>";
-    case 11: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q>";
+    case 11: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q (Q rounded in the kernel)>";
     case 16: return "shared_attn_fwd_sp_kernel<64 rows/wave, one wave per SIMD, software-pipelined>";
     case 17: return "shared_attn_fwd_tp_kernel<32 rows/wave, 8 waves, three-stage pipeline, MFMA/VALU interleave>";
+    case 14: return fold ? "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK, AdaIN fold>" : "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK>";
     case 10: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max>";
+    case 7: return "shared_attn_fwd_pipe_kernel<4 waves, exact rescale>";
     case 8: return "shared_attn_fwd_pp_kernel";
     default: return "shared_attn_fwd (tuning variant)";
   }

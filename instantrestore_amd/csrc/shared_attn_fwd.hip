@@ -416,6 +416,7 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 //    7 the same with an exact (every-change) rescale
 //   11 10 + pre-scaled Q, reference through the MFMA C operand (opt-in fast mode: one more rounding of Q)
 //   14 10 with the next tile's QK^T issued before the row max
+//   18 11 with the reference checked after the exponentials (no row max on ordinary tiles; K ring of 3)
 // Development builds only (-DIR_ABLATIONS; documented experiments): 1/2 this file's straight-line
 // kernel with 8 / 4 waves, 3/4 pipelined with register staging, 6 pipelined + builtin LDS-DMA, 8 ping-pong wave
 // groups (shared_attn_fwd_pp.hip), 9 straight schedule at 3 waves/SIMD, 15 the 64-row kernel with rotated phases;
@@ -423,10 +424,10 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 bool ir_attn_variant_available(int variant) {
   const int base = variant & 31;
 #ifdef IR_ABLATIONS
-  return base <= 17;
+  return base <= 18;
 #else
   if ((variant >> 5) != 0) return false;
-  return base == 0 || base == 7 || (base >= 10 && base <= 14);   // 16 (SP64) and 17 (TP32): development builds, like 1-6, 8, 9, 15
+  return base == 0 || base == 7 || (base >= 10 && base <= 14) || base == 18;   // 16 (SP64) and 17 (TP32): development builds, like 1-6, 8, 9, 15
 #endif
 }
 
@@ -464,13 +465,17 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
 #endif
   if (p.q_prescaled) {
     if ((base == 0 && ir_attn_default_is_w64(p)) || base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
-    return ir_launch_shared_attn_fwd_pipe(p, dtype, 11, s);   // the 32-row kernel's pre-scaled-Q form, minus its own Q rounding
+    // the 32-row kernel's pre-scaled-Q form (no Q rounding of its own), with the row max of every tile.  Its
+    // check-after-the-exponentials form (IR_TUNE_PIPE32_POSTCHECK, round 3) is parity-green and measures the SAME time
+    // on both short layer classes (profiles/r3_layer_classes_cfg2_presc.txt: this kernel is bound by its LDS fragment
+    // reads, not by vector instructions), at 8 KiB more LDS - so it stays opt-in
+    return ir_launch_shared_attn_fwd_pipe(p, dtype, base == 18 ? 18 : 11, s);
   }
   switch (base) {
     case 0:
       if (ir_attn_default_is_w64(p)) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
       return ir_launch_shared_attn_fwd_pipe(p, dtype, 14, s);
-    case 7: case 10: case 11: case 14: return ir_launch_shared_attn_fwd_pipe(p, dtype, base, s);
+    case 7: case 10: case 11: case 14: case 18: return ir_launch_shared_attn_fwd_pipe(p, dtype, base, s);
     case 12: return ir_launch_shared_attn_fwd_w64(p, dtype, s);
     case 13: return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
 #ifdef IR_ABLATIONS

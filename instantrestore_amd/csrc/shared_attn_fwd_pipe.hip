@@ -39,9 +39,14 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
   constexpr int NT = NW * 64;
   constexpr int QB = NW * 32;
   constexpr int CH = (KVB * 8) / NT;
-  constexpr int K_OFF = 0;                       // K ring: 2 tiles
-  constexpr int V_OFF = 2 * TILE_BYTES;          // V ring: 3 tiles
-  constexpr int OT_OFF = 5 * TILE_BYTES;         // folded total: 32 floats per thread
+  // CHK (pre-scaled Q only): no row max on ordinary tiles - the reference is checked AFTER the exponentials (below) and a
+  // tile that outgrew it is formed again from its K tile, which therefore stays in LDS one step longer: K ring of 3
+  constexpr bool CHK = (ABL & 8192) != 0;
+  static_assert(!CHK || (ABL & 2048), "the check after the exponentials needs scores that already carry the reference");
+  constexpr int KRING = CHK ? 3 : 2;
+  constexpr int K_OFF = 0;                       // K ring: 2 tiles (3 with CHK)
+  constexpr int V_OFF = KRING * TILE_BYTES;      // V ring: 3 tiles
+  constexpr int OT_OFF = (KRING + 3) * TILE_BYTES;   // folded total: 32 floats per thread
   constexpr int LDS_BYTES = OT_OFF + (FOLD ? NT * 32 * 4 : 0);
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -307,6 +312,9 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     const bool has1 = FAST || (t + 1 < NTILES), has2 = FAST || (t + 2 < NTILES);
     const unsigned char* Vb = smem + V_OFF + vcur * TILE_BYTES;
 
+    // K ring slots: tile t lives in slot t & 1 (ring of 2) or in the V ring's slot (ring of 3: both rings turn together)
+    const int v_next = vcur == 2 ? 0 : vcur + 1, v_prev = (vcur >= 1) ? vcur - 1 : 2;
+    const int ks_cur = CHK ? vcur : (t & 1), ks_next = CHK ? v_next : ((t + 1) & 1), ks_free = CHK ? v_prev : (t & 1);
     if (NOPIPE) {  // straight schedule: prefetch pair t+1, S(t) now
       if (has1) {
         issue_dma((t + 1) & 1, vcur == 2 ? 0 : vcur + 1);
@@ -321,10 +329,10 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     constexpr bool EARLYQK = (ABL & 4096) != 0 && !PRESC && !NOPIPE;
     if (EARLYQK) {
       if (has2) {
-        if (DMA) issue_dma(t & 1, (vcur >= 1) ? vcur - 1 : 2);
+        if (DMA) issue_dma(ks_free, v_prev);
         else issue_loads();
       }
-      if (has1) qk(n0, n1, (t + 1) & 1);
+      if (has1) qk(n0, n1, ks_next);
     }
     // (1) ragged tail of a segment: mask keys past its end (wave-uniform branch, rare)
     const int valid = c_len - ct0 * KVB;
@@ -337,19 +345,21 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
       }
     }
     // (2) row max of S(t): two v_max3 chains + one cross-half exchange
-    float mxa = max3(c0[0], c0[1], c0[2]);
-    float mxb = max3(c1[0], c1[1], c1[2]);
+    auto row_max = [&](const f32x16& a0, const f32x16& a1) {
+      float mxa = max3(a0[0], a0[1], a0[2]);
+      float mxb = max3(a1[0], a1[1], a1[2]);
 #pragma unroll
-    for (int r = 3; r < 15; r += 2) {
-      mxa = max3(mxa, c0[r], c0[r + 1]);
-      mxb = max3(mxb, c1[r], c1[r + 1]);
-    }
-    float mx = max3(mxa, mxb, max3(c0[15], c1[15], c1[15]));
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), mx);
-    }
-    if (PRESC) {
+      for (int r = 3; r < 15; r += 2) {
+        mxa = max3(mxa, a0[r], a0[r + 1]);
+        mxb = max3(mxb, a1[r], a1[r + 1]);
+      }
+      float m = max3(mxa, mxb, max3(a0[15], a1[15], a1[15]));
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+      return max3(__uint_as_float(sw[0]), __uint_as_float(sw[1]), m);
+    };
+    float mx = 0.f;
+    if (!CHK) mx = row_max(c0, c1);
+    if (PRESC && !CHK) {
       // S(t) is already c2*s - m_run.  First tile of the piece: adopt its row max whatever its sign (the
       // reference started at 0); later tiles: move only when some row grew by more than 2^6 (lazy).
       if (t == 0 || __any(mx > lazy_thr)) {
@@ -368,7 +378,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     // (3) rescale only when some row's max moved (exact).  LAZYMAX (experiment): keep the old
     // reference while no row's max grew by more than 2^6 in the exp2 domain, so P <= 64.
     constexpr bool LAZYMAX = (ABL & 1024) != 0;
-    if (PRESC) {
+    if (PRESC) {   // (CHK: nothing here - the check comes after the exponentials)
     } else if (LAZYMAX ? __any(mx > m_run + lazy_thr) : __any(m_new != m_run)) {
       const float alpha = fast_exp2((m_run - m_new) * c2);
 #pragma unroll
@@ -381,27 +391,75 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     // (4) the overlapped block: prefetch issue, S(t+1) on the matrix pipe, exp/pack on the VALU,
     //     PV(t) on the matrix pipe
     if (!EARLYQK && !NOPIPE && has2 && !(ABL & 4)) {
-      if (DMA) issue_dma(t & 1, (vcur >= 1) ? vcur - 1 : 2);  // K slot (t+2)&1, V slot (vcur+2)%3: both free since the last barrier
+      if (DMA) issue_dma(ks_free, v_prev);  // K slot of tile t+2 (ring of 2: (t+2)&1; of 3: (vcur+2)%3), V slot (vcur+2)%3: free since the last barrier
       else issue_loads();
     }
-    if (!EARLYQK && !NOPIPE && has1) qk(n0, n1, (t + 1) & 1);
+    if (!EARLYQK && !NOPIPE && has1) qk(n0, n1, ks_next);
     const f32x2 cc = {c2, c2};
     const f32x2 nm = {-mc, -mc};
-    if (!(ABL & 8))
+    f32x2 ta = {0.f, 0.f}, tb = {0.f, 0.f};   // CHK: this tile's own row sums (four 8-element partial sums per lane)
+    auto exps = [&]() {
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      f32x2 t0v = {c0[r], c0[r + 1]};
-      f32x2 t1v = {c1[r], c1[r + 1]};
-      if (!PRESC) {
-        t0v = __builtin_elementwise_fma(t0v, cc, nm);
-        t1v = __builtin_elementwise_fma(t1v, cc, nm);
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 t0v = {c0[r], c0[r + 1]};
+        f32x2 t1v = {c1[r], c1[r + 1]};
+        if (!PRESC) {
+          t0v = __builtin_elementwise_fma(t0v, cc, nm);
+          t1v = __builtin_elementwise_fma(t1v, cc, nm);
+        }
+        t0v[0] = fast_exp2(t0v[0]); t0v[1] = fast_exp2(t0v[1]);
+        t1v[0] = fast_exp2(t1v[0]); t1v[1] = fast_exp2(t1v[1]);
+        if (CHK) { ta += t0v; tb += t1v; }
+        else { la += t0v; lb += t1v; }
+        c0[r] = t0v[0]; c0[r + 1] = t0v[1];
+        c1[r] = t1v[0]; c1[r + 1] = t1v[1];
       }
-      t0v[0] = fast_exp2(t0v[0]); t0v[1] = fast_exp2(t0v[1]);
-      t1v[0] = fast_exp2(t1v[0]); t1v[1] = fast_exp2(t1v[1]);
-      la += t0v;
-      lb += t1v;
-      c0[r] = t0v[0]; c0[r + 1] = t0v[1];
-      c1[r] = t1v[0]; c1[r + 1] = t1v[1];
+    };
+    if (!CHK && !(ABL & 8)) exps();
+    if (CHK) {
+      // Reference checked AFTER the exponentials (the 64-row kernel's rule, shared_attn_fwd_w64.hip): the scores left the
+      // matrix pipe as exponents relative to the running reference, so P = exp2(S) needs no row max; what must be caught
+      // is a tile that OUTGROWS the reference.  Its own row sums show that: an 8-element partial sum above 2^11 means a
+      // probability above 2^8, inf/NaN an overflow.  Then - and always on the first tile of the walk, whose reference is
+      // still 0 - the scores are formed AGAIN (K tile still in LDS, P.V has not run, nothing of this tile was
+      // accumulated) and the exact path runs on them: row max, reference moved by d, accumulators, row sums and the
+      // already-formed S(t+1) shifted by d.  P <= 2^11 is harmless in the 16-bit operands (bf16 range; fp16 max 65504)
+      // and in the fp32 accumulators.
+      bool redo = (t == 0);
+      if (!redo) {
+        if (!(ABL & 8)) exps();
+        const float worst = max3(fmaxf(ta[0], ta[1]), tb[0], tb[1]);
+        redo = __any(!(worst <= 2048.f));
+        if (redo) {
+          qk(c0, c1, ks_cur);
+          asm volatile("s_nop 7\n\ts_nop 4" : "+v"(c0), "+v"(c1));   // MFMA -> asm v_max3 hazard pad
+          if (valid < KVB) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+              if (key >= valid) c0[r] = -INFINITY;
+              if (key + 32 >= valid) c1[r] = -INFINITY;
+            }
+          }
+        }
+      }
+      if (redo) {
+        const float mxr = row_max(c0, c1);
+        const float d = t == 0 ? mxr : (mxr > 0.f ? mxr : 0.f);
+        const float alpha = t == 0 ? 1.f : fast_exp2(-d);     // first tile: the accumulators are empty (and 0 * inf = NaN)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; c0[r] -= d; c1[r] -= d; n0[r] -= d; n1[r] -= d; }
+        la *= alpha;
+        lb *= alpha;
+        m_run += d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mneg[r] = -m_run;
+        ta = f32x2{0.f, 0.f};
+        tb = f32x2{0.f, 0.f};
+        exps();
+      }
+      la += ta;
+      lb += tb;
     }
     v8 pk[2][2];
     pk[0][0] = __builtin_convertvector(__builtin_shufflevector(c0, c0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
@@ -620,7 +678,10 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   int k = 1;
   if (p.ws != nullptr && rem > 0) {
     const size_t piece_bytes = (size_t)QB * 66 * sizeof(float);
-    k = ir_pick_split(rem, slots_x, p.ntiles / 8 /* pieces of at least 8 tiles */, (long)(p.ws_bytes / piece_bytes / 8));
+    // pieces of at least 8 tiles.  (Round 3 tried 5-tile pieces for the 16x16-token class - 320 items of 20 tiles on 512
+    // slots, cut in three - to put two workgroups on every CU: 47 us against 37 us unsplit, profiles/r3_layer_classes_cfg2_presc.txt:
+    // the prologue, the fp32 partials and the combine launch cost more than the idle slots.)
+    k = ir_pick_split(rem, slots_x, p.ntiles / 8, (long)(p.ws_bytes / piece_bytes / 8));
   }
   if (k <= 1) { full = p.sk_ix; rem = 0; k = 1; }
   p.sk_full = full;
@@ -648,6 +709,7 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   if (nw == 10) return fold ? launch<T, 4, true, 128 | 1024>(p, s) : launch<T, 4, false, 128 | 1024>(p, s);  // asm DMA + lazy max
   if (nw == 11) return fold ? launch<T, 4, true, 128 | 1024 | 2048>(p, s) : launch<T, 4, false, 128 | 1024 | 2048>(p, s);  // + pre-scaled Q, reference through the C operand
   if (nw == 14) return fold ? launch<T, 4, true, 128 | 1024 | 4096>(p, s) : launch<T, 4, false, 128 | 1024 | 4096>(p, s);  // + QK^T of the next tile first
+  if (nw == 18) return fold ? launch<T, 4, true, 128 | 1024 | 2048 | 8192>(p, s) : launch<T, 4, false, 128 | 1024 | 2048 | 8192>(p, s);  // 11 + reference checked after the exponentials
   return hipErrorInvalidValue;
 }
 

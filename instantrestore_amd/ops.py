@@ -456,8 +456,8 @@ _TUNING = int(os.environ.get("IR_ATTN_VARIANT", "0") or 0)
 
 def tuning_supports_prescaled_q() -> bool:
     """``IR_FLAG_Q_PRESCALED`` is implemented by the default dispatch and by the kernels it picks from (tuning 0, 11, 13,
-    17); under any other A/B ``tuning`` the processors keep the plain q (the C ABI rejects the combination)"""
-    return _TUNING in (0, 11, 13, 17)
+    17, 18); under any other A/B ``tuning`` the processors keep the plain q (the C ABI rejects the combination)"""
+    return _TUNING in (0, 11, 13, 17, 18)
 
 
 def set_attn_variant(variant: int) -> int:

@@ -227,7 +227,7 @@ def test_bf16_error_before_and_after_the_output_rounding():
     assert np.abs(s32.cpu().numpy().astype(np.float64) - ref2).max() <= 1e-3 and torch.equal(s32.to(dt), s16)
 
 
-@pytest.mark.parametrize("variant", [0, 11, 13], ids=["default", "pipe32", "w64x8qs"])
+@pytest.mark.parametrize("variant", [0, 11, 13, 18], ids=["default", "pipe32", "w64x8qs", "pipe32postcheck"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("shape", [(1, 1, 4096, 4, 4096, True, True), (1, 2, 1024, 2, 1024, False, False),
                                    (2, 1, 200, 3, 72, True, True), (1, 2, 64, 0, 0, True, False)],
@@ -273,15 +273,18 @@ def test_prescaled_q_contract(variant, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("case", ["ramp", "jump", "ragged_jump", "far_below_zero"])
-@pytest.mark.parametrize("variant", [13, 11], ids=["w64x8qs", "pipe32"])
+@pytest.mark.parametrize("case", ["ramp", "jump", "mid_jump", "ragged_jump", "far_below_zero"])
+@pytest.mark.parametrize("variant", [13, 18, 11], ids=["w64x8qs", "pipe32postcheck", "pipe32"])
 def test_reference_checked_after_the_exponentials(variant, case, dtype):
-    """The 64-row pre-scaled-Q kernel takes no row max on ordinary tiles: P = exp2(S - reference) first, and the tile's
-    own row sums say whether a score outgrew the reference (> 2^11 per lane, inf/NaN on overflow); then the scores are
-    formed again and the exact path moves the reference (csrc/shared_attn_fwd_w64.hip).  Inputs that drive that path:
+    """The pre-scaled-Q kernels (64-row; since round 3 also the 32-row one, IR_TUNE_PIPE32_POSTCHECK) take no row max on
+    ordinary tiles: P = exp2(S - reference) first, and the tile's own row sums say whether a score outgrew the reference
+    (an 8-element partial sum of a lane > 2^11, inf/NaN on overflow); then the scores are formed again and the exact path
+    moves the reference (csrc/shared_attn_fwd_w64.hip, csrc/shared_attn_fwd_pipe.hip).  Inputs that drive that path:
     scores growing tile after tile ("ramp": a rescale on most tiles), a jump of ~300 exponent units in a late reference
-    ("jump": exp2 overflows to inf before the check), the same behind a ragged tail, and a first tile whose scores
-    all lie far below the initial reference 0.  Against the float64 oracle, default tolerance, LSE included; the other
+    ("jump": exp2 overflows to inf before the check), a jump of ~9 units ("mid_jump": probabilities of several hundred
+    stay UNDER the 2^11 bound, so the reference does not move and P well above the old lazy rule's 2^6 reaches the P.V
+    product - the real invariant is P <= 2^11, harmless in bf16/fp16 operands and fp32 accumulators), the jump behind a
+    ragged tail, and a first tile whose scores all lie far below the initial reference 0.  Against the float64 oracle, default tolerance, LSE included; the other
     pre-scaled-Q kernels (exact row max) run the same inputs."""
     from instantrestore_amd import ops
     B, H, N = 1, 2, 3
@@ -295,10 +298,10 @@ def test_reference_checked_after_the_exponentials(variant, case, dtype):
     if case == "ramp":      # |k| grows along the key axis: later tiles hold larger and larger scores
         k = (k.float() * torch.linspace(0.2, 6.0, L).view(1, L, 1)).to(dtype)
         rk = (rk.float() * torch.linspace(6.0, 14.0, N * Lr).view(1, N, Lr, 1)).to(dtype)
-    elif case in ("jump", "ragged_jump"):   # one key direction shared by all queries, switched on late and hard
+    elif case in ("jump", "ragged_jump", "mid_jump"):   # one key direction shared by all queries, switched on late and hard
         d = torch.zeros(C); d[::2] = 1.0
         qp = (qp.float() + 2.0 * c * d).to(dtype)
-        rk[:, N - 1, Lr - 70:] = (rk[:, N - 1, Lr - 70:].float() + 30.0 * d).to(dtype)
+        rk[:, N - 1, Lr - 70:] = (rk[:, N - 1, Lr - 70:].float() + (0.8 if case == "mid_jump" else 30.0) * d).to(dtype)
     else:                   # every score of the walk's first tiles is hugely negative
         d = torch.ones(C)
         qp = (qp.float() + 1.5 * c * d).to(dtype)
@@ -316,7 +319,7 @@ def test_reference_checked_after_the_exponentials(variant, case, dtype):
                                                 include_self=True, adain=aff, q_prescaled=True)
     finally:
         ops.set_attn_variant(0)
-    assert {13: "w64", 11: "pipe"}[variant] in name, name
+    assert {13: "w64", 11: "pipe", 18: "pipe"}[variant] in name, name
     tol = {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
     o = out[:, rows].float().cpu().numpy().astype(np.float64)
     assert np.isfinite(o).all()

@@ -192,10 +192,49 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         # gfx950 correction of MI355X_MICROARCH.md.  null if the profile is not for this shape.
         "traffic": _pmc_traffic_bytes() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
         "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)" % _pmc_profile_name(),
-        "power_note": "this kernel runs at the 1400 W board cap on random data (profiles/r1_power_probe.txt): "
-                      "sustained shader clock 2.1-2.2 GHz against the 2.4 GHz the peak assumes; an MFMA-only stream of the same "
-                      "instruction holds 1.96 PFLOP/s on random operands under that cap (profiles/r1_ubench_mfma_power.txt)",
+        "power_note": "this kernel runs at the 1400 W board cap on random data (profiles/r2_power_probe.txt, "
+                      "r2_power_probe_postcheck.txt): sustained shader clock 2.2-2.25 GHz against the 2.4 GHz the peak assumes "
+                      "(0.894 ms at the cap vs 0.694 ms on all-zero inputs at full clock); an MFMA-only stream of the same instruction "
+                      "holds 1.75-1.8 PFLOP/s on random operands under that cap in the round-2 probes (profiles/r2_kernel_experiments.txt)",
     }
+
+
+def kernel_class_breakdown(layers, B, N, steps):
+    """GPU time of one step by kernel class, from HIP events recorded on the launch stream around every call into the
+    library during ``steps`` one-stream steps (the wrappers of ``instantrestore_amd.ops`` the processors call are
+    patched for the duration).  ms per step and share of the summed GPU time; classes: fused attention per token-axis
+    class (shared = over [self] ++ references, capture = plain self-attention of the reference token sets),
+    projection GEMMs per K, AdaIN statistics."""
+    from instantrestore_amd import ops
+    rec = []
+
+    def timed(fn, label):
+        def w(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **kw)
+            e1.record()
+            rec.append((label(*a, **kw), e0, e1))
+            return r
+        return w
+
+    saved = (ops.shared_attention, ops.linear, ops.adain_stats)
+    ops.shared_attention = timed(saved[0], lambda q, k, v, rk=None, rv=None, **kw:
+                                 "attention L=%d %s" % (q.shape[1], "shared" if rk is not None else "capture"))
+    ops.linear = timed(saved[1], lambda x, w, b=None, **kw: "projection GEMM K=%d" % w.shape[1])
+    ops.adain_stats = timed(saved[2], lambda v, rv, **kw: "AdaIN statistics")
+    try:
+        with torch.no_grad():
+            for _ in range(steps):
+                hot_path_step(layers, B, N, False, False)
+        torch.cuda.synchronize()
+    finally:
+        ops.shared_attention, ops.linear, ops.adain_stats = saved
+    tot = {}
+    for label, e0, e1 in rec:
+        tot[label] = tot.get(label, 0.0) + e0.elapsed_time(e1)
+    allms = sum(tot.values())
+    return {k: {"ms_per_step": round(v / steps, 4), "share": round(v / allms, 4)} for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
 
 
 def _pmc_profile_name():
@@ -343,15 +382,33 @@ def determinism_report(layers, B, N, reps=10):
 
 
 def extra_graph(layers, B, N, steps):
-    """the whole two-stream step captured in ONE hipGraph and replayed: same launches, same work, no CPU launch gaps"""
+    """the whole two-stream step captured in ONE hipGraph and replayed: same launches, same work, no CPU launch gaps.
+    Returns (seconds per replay, bit-identical?, detail): every layer output AND every harvested K/V tensor of three
+    replays is compared with a fresh eager two-stream run; a mismatch is reported per tensor together with whether the
+    eager run repeats itself (tests/test_gpu_determinism.py asserts all of it)."""
     cap = CapturedStep(layers, B, N)
     for _ in range(2):
         cap.replay()
     sec = _time_steps(cap.replay, steps)
-    ref = hot_path_step(layers, B, N, False, True)
+    ref = hot_path_step(layers, B, N, False, True, return_kv=True)
     torch.cuda.synchronize()
-    same = all(torch.equal(a, b) for a, b in zip(ref, cap.outs))
-    return sec, same
+    ref = [t.clone() for part in ref for t in part]
+    n = len(layers)
+    names = ["out%d" % i for i in range(n)] + ["key%d" % i for i in range(n)] + ["val%d" % i for i in range(n)]
+    bad = {}
+    for _ in range(3):
+        cap.replay()
+        torch.cuda.synchronize()
+        for name, a, b in zip(names, list(cap.outs) + list(cap.keys) + list(cap.vals), ref):
+            if not torch.equal(a, b):
+                bad[name] = max(bad.get(name, 0.0), float((a.float() - b.float()).abs().max()))
+    detail = {"tensors_compared": len(names), "replays_compared": 3}
+    if bad:
+        again = hot_path_step(layers, B, N, False, True, return_kv=True)
+        torch.cuda.synchronize()
+        detail.update({"mismatching": bad,
+                       "eager_repeats_itself": all(torch.equal(a, b) for a, b in zip([t for part in again for t in part], ref))})
+    return sec, not bad, detail
 
 
 def extra_e2e(B, N, px, dtype, steps, dev):
@@ -586,6 +643,16 @@ def main():
                 ms2 = sum(in_step_ms) / len(in_step_ms)
                 roof["in_step_two_streams"] = {"ms_per_launch": round(ms2, 4), "launches": len(in_step_ms),
                                                "note": "in the headline run: includes time shared with the other stream's kernels"}
+            # the WHOLE step against the same peak: algorithmic attention flops of all 18 layers / the headline step time
+            from instantrestore_amd.roofline import summary as _summary
+            sm = _summary(N, train_input, px)
+            step_tflop = B * (sm["shared_gflop_per_identity"] + sm["kv_capture_gflop_per_identity"]) / 1e3
+            step_ms = elapsed / args.steps * 1e3
+            roof["step"] = {"attention_tflop_per_step": round(step_tflop, 4), "achieved": round(step_tflop / step_ms * 1e3, 2),
+                            "frac": round(step_tflop / step_ms * 1e3 / roof["peak"], 4), "unit": "TFLOP/s",
+                            "note": "attention flops of the 9 capture + 9 shared layers / ms_per_step of the headline run; the "
+                                    "projections, AdaIN statistics and launch gaps are in the time and not in the flops",
+                            "kernel_classes_one_stream": kernel_class_breakdown(layers, B, N, max(2, args.steps // 2))}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(N, px, train_input, use_adain, seed=99)
     extras = None
@@ -598,9 +665,9 @@ def main():
                 extras["one_stream"] = {"images_per_s": round(B / sec1, 2), "ms_per_step": round(sec1 * 1e3, 4),
                                         "note": "same step, both UNets on one HIP stream (the reference's own schedule)"}
                 try:
-                    secg, same = extra_graph(layers, B, N, args.steps)
+                    secg, same, gdetail = extra_graph(layers, B, N, args.steps)
                     extras["hip_graph"] = {"images_per_s": round(B / secg, 2), "ms_per_step": round(secg * 1e3, 4),
-                                           "bit_identical_to_eager": bool(same),
+                                           "bit_identical_to_eager": bool(same), "compared": gdetail,
                                            "note": "the same two-stream step captured once in ONE hipGraph and replayed: same "
                                                    "launches, same work, no launch gaps"}
                 except Exception as e:   # capture is an extra: never lose the headline over it

@@ -88,6 +88,7 @@ def build_workload(cfg, train_input, dev, seed, act_fp32=True):
 _REF_STREAM = {}
 
 
+REF_STATS = {"on": True}      # A/B switch: False = every shared layer re-reads all reference V's for its AdaIN statistics also on one stream
 _AUTOCAST = {"dtype": None}   # set by main(): the 16-bit compute dtype the step autocasts to (None: inputs already 16 bit)
 
 
@@ -107,8 +108,8 @@ def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached
     fill 256 CUs on their own - overlap with the other UNet's kernels.  Same kernels, same work."""
     from instantrestore_amd.attn_processors import ReferenceCaptureComplete
     if cached_kv is not None:
-        keys, vals = cached_kv
-        return [ly["main_attn"](ly["h_main"], ref_keys=keys, ref_values=vals) for ly in layers]
+        keys, vals, stats = cached_kv if len(cached_kv) == 3 else (cached_kv[0], cached_kv[1], None)
+        return [ly["main_attn"](ly["h_main"], ref_keys=keys, ref_values=vals, ref_stats=stats) for ly in layers]
     cur = torch.cuda.current_stream()
     ref_stream = cur
     if two_streams:
@@ -119,8 +120,14 @@ def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached
     procs = [ly["kv_attn"].processor for ly in layers]
     for p in procs:
         p.stop_after_capture = procs if ref_early_exit else None
+    # AdaIN content statistics (mean / std of every reference V) once per reference in the capture layer - when that does
+    # not lengthen the critical path: with the two UNets on two streams the CAPTURE stream is the longer one (9 layers over
+    # B*N token sets against 9 over B), and moving the statistics there costs +0.3 ms (profiles/r3_ab_step.txt); there the
+    # shared layers keep computing them (ir_adain_stats) in the main stream's slack
+    use_stats = bool(layers[0]["main_attn"].processor.use_adain) and REF_STATS["on"] and not two_streams
     for p in procs:
         p.record_events = two_streams
+        p.capture_stats = use_stats    # AdaIN content statistics once per reference, on the capture stream (kv_harvest)
     with torch.cuda.stream(ref_stream):
         for ly in layers:
             try:
@@ -128,18 +135,19 @@ def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached
             except ReferenceCaptureComplete:
                 pass
     # 2. harvest (views) + zero-fill of invalid references (valid = N at inference, test.py:81)
-    keys, vals, events = [], [], []
+    keys, vals, events, stats = [], [], [], []
     for ly in layers:
         p = ly["kv_attn"].processor
         keys.append(p.keys.reshape(-1, N, p.keys.shape[1], p.keys.shape[2]))
         vals.append(p.values.reshape(-1, N, p.values.shape[1], p.values.shape[2]))
+        stats.append(None if p.v_mean is None else (p.v_mean.reshape(-1, N, *p.v_mean.shape[-2:]), p.v_std.reshape(-1, N, *p.v_std.shape[-2:])))
         events.append(p.ready)
         p.reset()
     # 3. shared attention on the degraded images (each layer waits for its own reference layer's event)
     outs = []
     for ly in layers:
         outs.append(ly["main_attn"](ly["h_main"], ref_keys=keys, ref_values=vals,
-                                    ref_events=events if two_streams else None))
+                                    ref_events=events if two_streams else None, ref_stats=stats if use_stats else None))
     if two_streams:
         cur.wait_stream(ref_stream)
     if return_kv:      # determinism checks compare the harvested K/V lists too
@@ -672,19 +680,21 @@ def main():
                                                    "launches, same work, no launch gaps"}
                 except Exception as e:   # capture is an extra: never lose the headline over it
                     extras["hip_graph"] = {"error": "%s: %s" % (type(e).__name__, e)}
-                keys, vals = [], []
-                for ly in layers:   # resident reference K/V of the batch's identities (what ReferenceKVCache.assemble returns)
+                keys, vals, cst = [], [], []
+                for ly in layers:   # resident reference K/V (+ AdaIN content statistics) of the batch's identities: what ReferenceKVCache.assemble returns
+                    ly["kv_attn"].processor.capture_stats = bool(use_adain)
                     with torch.autocast("cuda", dtype=dtype):
                         ly["kv_attn"](ly["h_ref"])
                     p = ly["kv_attn"].processor
                     keys.append(p.keys.reshape(-1, N, *p.keys.shape[1:]).clone())
                     vals.append(p.values.reshape(-1, N, *p.values.shape[1:]).clone())
+                    cst.append(None if p.v_mean is None else (p.v_mean.reshape(-1, N, *p.v_mean.shape[-2:]).clone(), p.v_std.reshape(-1, N, *p.v_std.shape[-2:]).clone()))
                     p.reset()
-                secc = _time_steps(lambda: hot_path_step(layers, B, N, cached_kv=(keys, vals)), args.steps)
+                secc = _time_steps(lambda: hot_path_step(layers, B, N, cached_kv=(keys, vals, cst if use_adain else None)), args.steps)
                 extras["kv_cached"] = {"images_per_s": round(B / secc, 2), "ms_per_step": round(secc * 1e3, 4),
                                        "note": "reference K/V served from the per-identity cache (SURVEY 8f rank 2): only the nine "
                                                "shared layers run; valid when the references of an identity repeat across frames"}
-                del keys, vals
+                del keys, vals, cst
                 if args.config != "cfg5":
                     try:
                         extras["e2e_topology_host"] = extra_e2e(B, N, px, dtype, max(2, args.steps // 2), dev)

@@ -170,6 +170,21 @@ int ir_adain_stats(int32_t dtype, int32_t batch, int32_t heads, int32_t len_self
                    int32_t len_ref, const void* v_self, int64_t vs_sb, int64_t vs_sl, int64_t vs_sh,
                    const void* v_ref, int64_t vr_sb, int64_t vr_sn, int64_t vr_sl, int64_t vr_sh,
                    float eps, float* a, float* b, void* workspace, size_t workspace_bytes, void* stream);
+/*
+ * ir_adain_stats_cached - the same affine when the CONTENT statistics are already known.
+ *
+ * mean(v_ref_n) and std(v_ref_n) of a reference V do not change while the identity's references do not
+ * (pix2pix_turbo.py:255-266 recomputes them every frame): the K/V-capture layer emits them once with ir_token_stats
+ * (content_mean, content_std: fp32 (B, N, H, 64) contiguous, std WITHOUT the eps) and every frame reads only v_self,
+ * 1/(N+1) of the bytes.  Bit-identical (a, b) to ir_adain_stats on the same tensors: both run the same partial kernel
+ * and the same merge order.  A reference zero-filled by ir_zero_invalid_refs has statistics (0, 0): the caller zeroes
+ * its cached entries (instantrestore_amd/kv_harvest.py does).
+ *   workspace: >= ir_adain_stats_workspace_bytes(batch, heads, len_self, 0, len_self)
+ */
+int ir_adain_stats_cached(int32_t dtype, int32_t batch, int32_t heads, int32_t len_self, int32_t n_refs,
+                          const void* v_self, int64_t vs_sb, int64_t vs_sl, int64_t vs_sh,
+                          const float* content_mean, const float* content_std,
+                          float eps, float* a, float* b, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * ir_token_stats - mean and UNBIASED standard deviation over the token axis.

@@ -57,6 +57,7 @@ SYMBOLS = {
     "ir_adain_stats_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32]),
     "ir_adain_stats": (C.c_int, [i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, vp, i64, i64, i64, i64,
                                  f32, vp, vp, vp, C.c_size_t, vp]),
+    "ir_adain_stats_cached": (C.c_int, [i32, i32, i32, i32, i32, vp, i64, i64, i64, vp, vp, f32, vp, vp, vp, C.c_size_t, vp]),
     "ir_token_stats": (C.c_int, [i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp, vp, C.c_size_t, vp]),
     "ir_adain_apply": (C.c_int, [i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp,
                                  vp, i64, i64, i64, i64, vp]),

@@ -228,12 +228,23 @@ class AttnProcessor(nn.Module):
         self.record_events = False        # True: record `ready` on the current stream once K/V are stashed
         self.ready = None
         self.stream = None                # HIP stream the K/V were produced on (kv_harvest orders its zero fill after it)
+        self.capture_stats = False        # True (kv_harvest.enable_ref_stats): also stash the AdaIN CONTENT statistics of
+        self.v_mean, self.v_std = None, None   # every reference V, fp32 (B*N, H, 64) - constant per identity
 
     def reset(self):
         self.keys, self.values = None, None
         self.is_self_attn = None
         self.ready = None
         self.stream = None
+        self.v_mean, self.v_std = None, None
+
+    def _stash_stats(self, attn):
+        """mean and unbiased std over the tokens of every captured V, per (head, channel): the content statistics of
+        ``adain`` (attn_processors.py:9-10) computed HERE, once per reference and on the capture stream, instead of in
+        every shared layer of every frame"""
+        if self.capture_stats and self.values.is_cuda:
+            m, sd = _ops.token_stats(self.values.unsqueeze(1), heads=attn.heads)      # (B*N, 1, H, 64) each
+            self.v_mean, self.v_std = m[:, 0], sd[:, 0]
 
     def _mark_ready(self):
         if self.keys.is_cuda:
@@ -250,10 +261,12 @@ class AttnProcessor(nn.Module):
             # every other capturing layer has run: this is the last one, and only its to_k / to_v are still
             # needed - no query, no attention, no out projection
             self.keys, self.values = _project_kv_only(attn, st)
+            self._stash_stats(attn)
             self._mark_ready()
             raise ReferenceCaptureComplete()
         query, key, value, presc = _project_qkv(attn, st)
         self.keys, self.values = key, value  # consumed in place by the shared layers: no copies
+        self._stash_stats(attn)
         self._mark_ready()
         _same_16bit(query, key, value)
         kw = {"q_prescaled": True} if presc else {}
@@ -282,7 +295,7 @@ class FaceIDAttnProcessor(nn.Module):
         self.is_self_attn = None
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                ref_keys=None, ref_values=None, ref_events=None):  # ref_* accepted and ignored, like the reference
+                ref_keys=None, ref_values=None, ref_events=None, ref_stats=None):  # ref_* accepted and ignored, like the reference
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         self.is_self_attn = encoder_hidden_states is None
         query = attn.to_q(st.hidden)
@@ -315,7 +328,7 @@ class SharedAttnProcessor(nn.Module):
         self.train_input = train_input
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                ref_keys=None, ref_values=None, ref_events=None):
+                ref_keys=None, ref_values=None, ref_events=None, ref_stats=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         query, key, value, presc = _project_qkv(attn, st)
 
@@ -325,6 +338,7 @@ class SharedAttnProcessor(nn.Module):
         if self.self_attn_idx is not None and ref_keys is not None and ref_values is not None:
             ref_k = ref_keys[self.self_attn_idx]
             ref_v = ref_values[self.self_attn_idx]
+            cstats = ref_stats[self.self_attn_idx] if ref_stats is not None else None
             if ref_events is not None and ref_events[self.self_attn_idx] is not None:
                 # the reference UNet runs on another HIP stream (kv_harvest with_events): this layer needs
                 # capture layer `self_attn_idx` and nothing later
@@ -332,10 +346,18 @@ class SharedAttnProcessor(nn.Module):
                 cur.wait_event(ref_events[self.self_attn_idx])
                 ref_k.record_stream(cur)
                 ref_v.record_stream(cur)
+                if cstats is not None:
+                    cstats[0].record_stream(cur)
+                    cstats[1].record_stream(cur)
             include_self = bool(self.train_input)
             if self.use_adain:
-                # style = this image's own post-projection V; content = each reference V
-                affine = _ops.adain_stats(value, ref_v, heads=attn.heads)
+                # style = this image's own post-projection V; content = each reference V.  With the content statistics
+                # handed over (``ref_stats``: computed once per identity by the K/V-capture layer, kv_harvest with_stats)
+                # only V_self is read here - 1/(N+1) of the bytes, the same (a, b) bit for bit
+                if cstats is not None:
+                    affine = _ops.adain_stats_cached(value, cstats[0], cstats[1], heads=attn.heads)
+                else:
+                    affine = _ops.adain_stats(value, ref_v, heads=attn.heads)
         _same_16bit(query, key, value, ref_k, ref_v)
 
         want_probs = bool(self.save_self_attentions)

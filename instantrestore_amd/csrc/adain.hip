@@ -260,6 +260,113 @@ __global__ void __launch_bounds__(256) adain_finalize_staged_kernel(const AdainK
   }
 }
 
+// ---- AdaIN affine from CACHED content statistics (round 3) ---------------------------------------------------------
+// The content statistics (mu_x, sigma_x) of a reference V are constant per identity: the K/V-capture layer emits them
+// once (ir_token_stats: the same partial kernel and chunk merge as above, so the same bits) and the shared layer reads
+// only V_self - 1/(N+1) of the bytes - to finalise a = (sigma_v + eps) / (sigma_x + eps), b = mu_v - mu_x * a.
+// Self partials: adain_partial_kernel over the B self matrices alone (ws layout [b][h][chunk][128]).
+// grid: (B*H); 256 threads; dynamic LDS: nchunk * 128 floats of partials + 128 of the merged self statistics.
+__global__ void __launch_bounds__(256) adain_finalize_cached_kernel(const AdainKParams p) {
+  extern __shared__ __attribute__((aligned(16))) float csm[];
+  const int tid = threadIdx.x;
+  const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
+  const int nch = (p.Ls + ROWS - 1) / ROWS;
+  const int per_mat = p.nchunk * 128;
+  const float* g = p.ws + (((int64_t)b * p.H + h) * p.nchunk) * 128;
+  for (int i = tid * 4; i < nch * 128; i += 256 * 4) *(f32x4*)&csm[i] = *(const f32x4*)&g[i];
+  __syncthreads();
+  float* stats = csm + per_mat;   // mean[64] | M2[64] of V_self
+  if (tid < 64) {
+    const int d = tid;
+    float cn = 0.f, mean = 0.f, m2 = 0.f;
+    for (int c = 0; c < nch; ++c) {
+      const int rows = (c + 1) * ROWS <= p.Ls ? ROWS : p.Ls - c * ROWS;
+      chan_merge(cn, mean, m2, (float)rows, csm[c * 128 + d], csm[c * 128 + 64 + d]);
+    }
+    stats[d] = mean;
+    stats[64 + d] = m2;
+  }
+  __syncthreads();
+  for (int i = tid; i < p.N * 64; i += 256) {
+    const int n = i >> 6, d = i & 63;
+    const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
+    const float sd_v = sqrtf(stats[64 + d] / (float)(p.Ls - 1)) + p.eps;
+    const float sd_x = p.cstd[o] + p.eps;     // cstd = sqrtf(M2_x / (Lr - 1)): the expression of the uncached kernels
+    const float a = sd_v / sd_x;
+    p.a[o] = a;
+    p.b[o] = stats[d] - p.cmean[o] * a;
+  }
+}
+
+// One-chunk token axes (the 16x16-token class): one workgroup per (b, h) reads V_self and emits the affine. grid: (H, B).
+template <typename T>
+__global__ void __launch_bounds__(AT) adain_self_small_kernel(const AdainKParams p) {
+  using v8 = typename ElemTraits<T>::v8;
+  __shared__ float red[32][8][17];
+  __shared__ float stats[128];
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, slot = tid & 7, rs = tid >> 3;
+  constexpr int PER = ROWS / 32;
+  const T* base = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
+  v8 xs[PER];
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    const int r = rs + it * 32;
+    xs[it] = *(const v8*)(base + (int64_t)(r < p.Ls ? r : p.Ls - 1) * p.vs_sl + slot * 8);
+  }
+  float cnt = 0.f, K[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { K[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll
+  for (int it = 0; it < PER; ++it) {
+    if (rs + it * 32 < p.Ls) {
+      const f32x8 f = __builtin_convertvector(xs[it], f32x8);
+      if (cnt == 0.f) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) K[i] = f[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float d = f[i] - K[i];
+        s1[i] += d;
+        s2[i] = __builtin_fmaf(d, d, s2[i]);
+      }
+      cnt += 1.f;
+    }
+  }
+  {
+    float* o = &red[rs][slot][0];
+    o[0] = cnt;
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      o[1 + i] = K[i] + s1[i] * inv;
+      o[9 + i] = s2[i] - s1[i] * s1[i] * inv;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int cs = tid >> 3, ci = tid & 7;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < 32; ++k) {
+      const float* o = &red[k][cs][0];
+      chan_merge(n, mean, m2, o[0], o[1 + ci], o[9 + ci]);
+    }
+    stats[tid] = mean;
+    stats[64 + tid] = m2;
+  }
+  __syncthreads();
+  for (int i = tid; i < p.N * 64; i += AT) {
+    const int n = i >> 6, d = i & 63;
+    const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
+    const float sd_v = sqrtf(stats[64 + d] / (float)(p.Ls - 1)) + p.eps;
+    const float sd_x = p.cstd[o] + p.eps;
+    const float a = sd_v / sd_x;
+    p.a[o] = a;
+    p.b[o] = stats[d] - p.cmean[o] * a;
+  }
+}
+
 // grid: (B*(1+N)*H); 64 threads. Plain token statistics (mean, unbiased std) of every matrix.
 __global__ void __launch_bounds__(64) token_stats_finalize_kernel(const AdainKParams p) {
   const int d = threadIdx.x;
@@ -346,6 +453,24 @@ hipError_t ir_launch_token_stats(const AdainKParams& p, int dtype, hipStream_t s
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(token_stats_finalize_kernel, dim3(p.B * (1 + p.N) * p.H), dim3(64), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t ir_launch_adain_stats_cached(const AdainKParams& p, int dtype, hipStream_t s) {
+  if (p.nchunk == 1) {
+    if (dtype == 1) hipLaunchKernelGGL((adain_self_small_kernel<__bf16>), dim3(p.H, p.B), dim3(AT), 0, s, p);
+    else hipLaunchKernelGGL((adain_self_small_kernel<_Float16>), dim3(p.H, p.B), dim3(AT), 0, s, p);
+    return hipGetLastError();
+  }
+  AdainKParams q = p;
+  q.N = 0;                                   // the partial pass sees B matrices: the self V's
+  const dim3 grid(p.nchunk, p.H, p.B);
+  if (dtype == 1) hipLaunchKernelGGL((adain_partial_kernel<__bf16>), grid, dim3(AT), 0, s, q);
+  else hipLaunchKernelGGL((adain_partial_kernel<_Float16>), grid, dim3(AT), 0, s, q);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const size_t lds = (size_t)(p.nchunk * 128 + 128) * sizeof(float);
+  hipLaunchKernelGGL(adain_finalize_cached_kernel, dim3(p.B * p.H), dim3(256), lds, s, p);
   return hipGetLastError();
 }
 

@@ -206,6 +206,33 @@ int ir_adain_stats(int32_t dtype, int32_t batch, int32_t heads, int32_t len_self
   return IR_OK;
 }
 
+int ir_adain_stats_cached(int32_t dtype, int32_t batch, int32_t heads, int32_t len_self, int32_t n_refs,
+                          const void* v_self, int64_t vs_sb, int64_t vs_sl, int64_t vs_sh,
+                          const float* content_mean, const float* content_std,
+                          float eps, float* a, float* b, void* workspace, size_t workspace_bytes, void* stream) {
+  if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d", dtype);
+  if (batch <= 0 || heads <= 0 || len_self <= 0 || n_refs <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (!v_self || !content_mean || !content_std || !a || !b || !workspace) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  if (!aligned16(v_self)) return fail(IR_ERR_UNSUPPORTED, "v_self must be 16-byte aligned");
+  const int64_t st[] = {vs_sb, vs_sl, vs_sh};
+  for (int64_t s : st) if (!stride_ok(s)) return fail(IR_ERR_UNSUPPORTED, "stride %lld must be a non-negative multiple of 8", (long long)s);
+  const size_t need = ir_adain_stats_workspace_bytes(batch, heads, len_self, 0, len_self);
+  if (workspace_bytes < need) return fail(IR_ERR_WORKSPACE, "workspace %zu < %zu bytes", workspace_bytes, need);
+  AdainKParams p;
+  memset(&p, 0, sizeof(p));
+  p.v_self = v_self; p.v_ref = v_self;
+  p.vs_sb = vs_sb; p.vs_sl = vs_sl; p.vs_sh = vs_sh;
+  p.ws = (float*)workspace; p.a = a; p.b = b;
+  p.B = batch; p.H = heads; p.Ls = len_self; p.N = n_refs; p.Lr = len_self;
+  p.nchunk = adain_nchunk(len_self, len_self);
+  if ((size_t)(p.nchunk * 128 + 128) * sizeof(float) > 60 * 1024) return fail(IR_ERR_UNSUPPORTED, "len_self %d: too many chunks", len_self);
+  p.eps = eps;
+  p.cmean = content_mean; p.cstd = content_std;
+  const hipError_t e = ir_launch_adain_stats_cached(p, dtype, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "adain_stats_cached launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
 int ir_token_stats(int32_t dtype, int32_t batch, int32_t heads, int32_t n_mats, int32_t len,
                    const void* x, int64_t x_sb, int64_t x_sn, int64_t x_sl, int64_t x_sh,
                    float* mean, float* std, void* workspace, size_t workspace_bytes, void* stream) {

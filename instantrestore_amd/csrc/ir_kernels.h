@@ -61,6 +61,10 @@ struct AdainKParams {
   int B, H, Ls, N, Lr;
   int nchunk;         // max(ceil(Ls/ROWS), ceil(Lr/ROWS))
   float eps;
+  // ir_adain_stats_cached: content statistics (mean, unbiased std) of every reference V, (B, N, H, 64) fp32, computed once
+  // per identity (ir_token_stats in the K/V-capture layer); only V_self is read here
+  const float* cmean;
+  const float* cstd;
 };
 
 struct AdainApplyKParams {
@@ -113,6 +117,7 @@ hipError_t ir_launch_shared_attn_fwd_pp(const AttnKParams& p, int dtype, hipStre
 hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_token_stats(const AdainKParams& p, int dtype, hipStream_t s);
+hipError_t ir_launch_adain_stats_cached(const AdainKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_adain_apply(const AdainApplyKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_zero_refs(const ZeroRefsKParams& p, hipStream_t s);
 hipError_t ir_launch_tensor2im(const void* x, void* out, int dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw,

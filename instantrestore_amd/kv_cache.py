@@ -18,7 +18,7 @@ from typing import Callable, Hashable, List, Sequence, Tuple
 
 import torch
 
-KV = Tuple[List[torch.Tensor], List[torch.Tensor]]
+KV = Tuple[List[torch.Tensor], ...]   # (keys, values) or (keys, values, stats): stats[l] = (mean, std) fp32 (1, N, H, 64)
 
 
 class ReferenceKVCache:
@@ -37,13 +37,17 @@ class ReferenceKVCache:
         return identity in self._store
 
     def get_or_compute(self, identity: Hashable, compute: Callable[[], KV]) -> KV:
-        """``compute()`` must return ``(keys, values)`` for ONE identity: lists of ``(1, N, L, C)``."""
+        """``compute()`` must return ``(keys, values)`` for ONE identity: lists of ``(1, N, L, C)`` - or ``(keys, values,
+        stats)`` as ``get_conditioning_keys_values(..., with_stats=True)`` does: the AdaIN content statistics of the reference
+        V's (``(mean, std)`` per layer, fp32 ``(1, N, H, 64)``) are constant per identity too and are cached with them."""
         if identity in self._store:
             self._store.move_to_end(identity)
             self.hits += 1
             return self._store[identity]
         self.misses += 1
-        keys, values = compute()
+        res = compute()
+        keys, values = res[0], res[1]
+        stats = res[2] if len(res) > 2 else None
         if len(keys) != len(values) or any(k.shape[0] != 1 or k.shape != v.shape for k, v in zip(keys, values)):
             raise ValueError("compute() must return matching lists of (1, N, L, C) tensors")
         # compact copies: the harvested tensors are strided views of the capture layers' fused (B*N, L, 3C) projection
@@ -51,6 +55,8 @@ class ReferenceKVCache:
         # entry and eviction would free nothing.  One entry = 2 * 9 layers * N * L * C * 2 bytes.
         entry = ([k.detach().clone(memory_format=torch.contiguous_format) for k in keys],
                  [v.detach().clone(memory_format=torch.contiguous_format) for v in values])
+        if stats is not None:
+            entry = entry + ([None if st is None else (st[0].detach().clone(), st[1].detach().clone()) for st in stats],)
         self._store[identity] = entry
         while len(self._store) > self.max_identities:
             self._store.popitem(last=False)
@@ -64,12 +70,18 @@ class ReferenceKVCache:
         n_layers = len(entries[0][0])
         keys = [torch.cat([e[0][l] for e in entries], dim=0) for l in range(n_layers)]
         values = [torch.cat([e[1][l] for e in entries], dim=0) for l in range(n_layers)]
+        if all(len(e) > 2 for e in entries):
+            stats = [None if any(e[2][l] is None for e in entries) else
+                     (torch.cat([e[2][l][0] for e in entries], dim=0), torch.cat([e[2][l][1] for e in entries], dim=0))
+                     for l in range(n_layers)]
+            return keys, values, stats
         return keys, values
 
     def nbytes(self, identity: Hashable) -> int:
         """device bytes held for one cached identity"""
-        ks, vs = self._store[identity]
-        return sum(t.untyped_storage().nbytes() for t in ks + vs)
+        e = self._store[identity]
+        extra = [t for st in (e[2] if len(e) > 2 else []) if st is not None for t in st]
+        return sum(t.untyped_storage().nbytes() for t in e[0] + e[1] + extra)
 
     def invalidate(self, identity: Hashable = None) -> None:
         if identity is None:

@@ -21,16 +21,22 @@ from . import ops as _ops
 
 
 def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int],
-                         reset: bool = True, with_events: bool = False):
+                         reset: bool = True, with_events: bool = False, with_stats: bool = False):
     """``(keys, values)`` - or ``(keys, values, events)`` with ``with_events``: one HIP event per layer,
     recorded by the capturing processor right after its K/V projections when ``record_events`` was set on
     it (see :func:`enable_stream_overlap`); hand them to the main UNet as
     ``cross_attention_kwargs={'ref_keys': ..., 'ref_values': ..., 'ref_events': ...}`` when the two UNets
-    run on different streams."""
+    run on different streams.
+
+    ``with_stats`` appends ``stats``: per layer ``(mean, std)`` of every reference V over its tokens, fp32
+    ``(B, N, H, 64)`` - the CONTENT statistics of AdaIN (attn_processors.py:9-10), stashed by the capturing processors
+    (:func:`enable_ref_stats`) or computed here when they were not; pass it on as ``'ref_stats'`` and the shared layers
+    read only their own V (``ir_adain_stats_cached``).  References zero-filled below get the statistics of an all-zero
+    V, (0, 0): exactly what the uncached path computes from the zeroed tensor (the ``b == mean(V_self)`` quirk)."""
     procs = [p for p in original_unet.attn_processors.values() if type(p) in [_ap.AttnProcessor]]
     if not procs:
         raise RuntimeError("no AttnProcessor on this UNet: call register_attention_processor_kv_unet first")
-    keys, values, events, streams = [], [], [], []
+    keys, values, events, streams, stats = [], [], [], [], []
     for p in procs:
         if p.keys is None or p.values is None:
             raise RuntimeError("reference UNet has not been run since the last reset()")
@@ -40,6 +46,16 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
         v = p.values.reshape(-1, n_refs, p.values.shape[1], p.values.shape[2])
         keys.append(k)
         values.append(v)
+        if with_stats:
+            m, sd = getattr(p, "v_mean", None), getattr(p, "v_std", None)
+            if m is None and v.is_cuda:      # not stashed at capture time: one pass over V now, behind its producer
+                cur = torch.cuda.current_stream(v.device)
+                if streams[-1] is not None and streams[-1] != cur:
+                    cur.wait_stream(streams[-1])
+                    v.record_stream(cur)
+                heads = v.shape[-1] // _ops.HEAD_DIM
+                m, sd = _ops.token_stats(v, heads=heads)
+            stats.append(None if m is None else (m.reshape(-1, n_refs, *m.shape[-2:]), sd.reshape(-1, n_refs, *sd.shape[-2:])))
     valid = torch.as_tensor(valid_indices)
     if bool((valid < n_refs).any()):
         if keys[0].is_cuda:
@@ -56,6 +72,14 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
                 v.record_stream(cur)
         for k, v in zip(keys, values):
             _ops.zero_invalid_refs(k, v, valid, heads=k.shape[-1] // _ops.HEAD_DIM)
+        if with_stats and keys[0].is_cuda:
+            # the zero fill invalidates the cached statistics of the zeroed references: an all-zero V has mean 0, std 0
+            keep = (torch.arange(n_refs)[None, :] < valid.reshape(-1, 1)).to(device=keys[0].device, dtype=torch.float32)[:, :, None, None]
+            for st in stats:
+                if st is not None:
+                    for t in st:
+                        t.record_stream(torch.cuda.current_stream(t.device))
+                        t.mul_(keep)
     if reset:
         for p in procs:
             p.reset()
@@ -65,8 +89,17 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
             ev = torch.cuda.Event()
             ev.record()
             events = [ev] * len(keys)
-        return keys, values, events
-    return keys, values
+        return (keys, values, events, stats) if with_stats else (keys, values, events)
+    return (keys, values, stats) if with_stats else (keys, values)
+
+
+def enable_ref_stats(original_unet, enabled: bool = True) -> None:
+    """make every K/V-capturing processor also stash the AdaIN content statistics of its V (``AttnProcessor.v_mean`` /
+    ``v_std``): they are computed once per reference, on the stream the reference UNet runs on, and
+    :func:`harvest_reference_kv` ``(with_stats=True)`` hands them to the main UNet"""
+    for p in original_unet.attn_processors.values():
+        if type(p) in [_ap.AttnProcessor]:
+            p.capture_stats = bool(enabled)
 
 
 def enable_stream_overlap(original_unet, enabled: bool = True) -> None:
@@ -79,7 +112,8 @@ def enable_stream_overlap(original_unet, enabled: bool = True) -> None:
 
 
 def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, timestep, encoder_hidden_states,
-                                 n_refs: int, valid_indices: Sequence[int], early_exit: bool = False):
+                                 n_refs: int, valid_indices: Sequence[int], early_exit: bool = False,
+                                 with_stats: bool = False):
     """Run the frozen reference UNet on the (already encoded and noised) reference latents
     ``(B*N, 4, S, S)`` and harvest.  VAE encode/decode, the scheduler and the caption encoder
     around it (pix2pix_turbo.py:244-257, 277-278) are stock PyTorch and out of scope.
@@ -88,9 +122,11 @@ def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, times
     thrown away by the inference caller (``inference/test.py:100`` keeps only the K/V lists), so its
     forward can stop at the last K/V-capturing layer - after ``to_k`` / ``to_v`` of that layer, before its
     attention, its out projection and everything downstream.  The harvested lists are identical."""
+    if with_stats:
+        enable_ref_stats(original_unet, True)
     if not early_exit:
         original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
-        return harvest_reference_kv(original_unet, n_refs, valid_indices)
+        return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats)
     procs = [p for p in original_unet.attn_processors.values() if type(p) in [_ap.AttnProcessor]]
     if not procs:
         raise RuntimeError("no AttnProcessor on this UNet: call register_attention_processor_kv_unet first")
@@ -106,4 +142,4 @@ def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, times
     finally:
         for p in procs:
             p.stop_after_capture = None
-    return harvest_reference_kv(original_unet, n_refs, valid_indices)
+    return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats)

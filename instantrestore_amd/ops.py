@@ -284,6 +284,35 @@ def adain_stats(v_self: torch.Tensor, ref_v: torch.Tensor, *, heads: int, eps: f
 
 
 @_on_tensor_device
+def adain_stats_cached(v_self: torch.Tensor, content_mean: torch.Tensor, content_std: torch.Tensor, *, heads: int,
+                       eps: float = ADAIN_EPS):
+    """The affine of :func:`adain_stats` from CACHED content statistics (``ir_adain_stats_cached``): ``content_mean`` /
+    ``content_std`` are the fp32 ``(B, N, H, 64)`` outputs of :func:`token_stats` over the reference V's (the K/V-capture
+    layer computes them once per identity); only ``v_self`` is read.  Bit-identical to ``adain_stats(v_self, ref_v)``."""
+    _need_gpu(v_self, content_mean, content_std)
+    _forward_only(v_self)
+    v_self = _tok(v_self, heads, "v_self")
+    B, Ls, _ = v_self.shape
+    if content_mean.dim() != 4 or content_mean.shape != content_std.shape or content_mean.shape[0] != B or \
+            tuple(content_mean.shape[2:]) != (heads, HEAD_DIM):
+        raise ValueError(f"content statistics must be two (B, N, {heads}, 64) tensors")
+    for t in (content_mean, content_std):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("content statistics must be contiguous fp32")
+    N = content_mean.shape[1]
+    L = _lib.lib()
+    nbytes = L.ir_adain_stats_workspace_bytes(B, heads, Ls, 0, Ls)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=v_self.device)
+    a = torch.empty((B, N, heads, HEAD_DIM), dtype=torch.float32, device=v_self.device)
+    b = torch.empty_like(a)
+    rc = L.ir_adain_stats_cached(_dtype_code(v_self), B, heads, Ls, N, v_self.data_ptr(), v_self.stride(0), v_self.stride(1),
+                                 HEAD_DIM, content_mean.data_ptr(), content_std.data_ptr(), float(eps), a.data_ptr(),
+                                 b.data_ptr(), ws.data_ptr(), nbytes, _stream())
+    _lib.check(rc, "ir_adain_stats_cached")
+    return a, b
+
+
+@_on_tensor_device
 def token_stats(x: torch.Tensor, *, heads: int):
     """mean and unbiased std over the token axis of x (B, M, L, H*64) -> two fp32 (B, M, H, 64)
     tensors (``ir_token_stats``)."""

@@ -1,0 +1,79 @@
+"""AdaIN content statistics computed ONCE per identity: the K/V-capture layer emits (mean, std) of every
+reference V (ir_token_stats), the shared layer reads only V_self (ir_adain_stats_cached).  The affine must be the SAME BITS as
+ir_adain_stats on the same tensors (same partial kernel, same merge order), the zero-reference quirk of the reference
+(attn_processors.py:242-246 on a zero-filled V: b == mean(V_self) exactly, pix2pix_turbo.py:269-273) must survive the cache -
+the zero fill invalidates the cached statistics of the zeroed references - and the shared processor's output must not change
+by a bit when ``ref_stats`` is handed over."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("B,H,L,N,Lr", [(8, 20, 256, 4, 256), (8, 10, 1024, 4, 1024), (8, 5, 4096, 4, 4096), (2, 3, 300, 3, 300),
+                                        (1, 2, 200, 8, 200), (2, 5, 16384, 2, 16384), (3, 2, 7, 2, 7)])
+def test_cached_affine_is_bit_identical(dtype, B, H, L, N, Lr):
+    from instantrestore_amd import ops
+    g = torch.Generator().manual_seed(L + N)
+    C = H * 64
+    v = (torch.randn(B, L, C, generator=g) * 0.8 + 0.3).to(dtype).cuda()
+    rv = (torch.randn(B, N, Lr, C, generator=g) * 1.7 - 0.2).to(dtype).cuda()
+    a0, b0 = ops.adain_stats(v, rv, heads=H)
+    # statistics as the capture layer stashes them: one (B*N, 1, L, C) call over the flat reference token sets
+    m, sd = ops.token_stats(rv.reshape(B * N, 1, Lr, C), heads=H)
+    a1, b1 = ops.adain_stats_cached(v, m.reshape(B, N, H, 64), sd.reshape(B, N, H, 64), heads=H)
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)
+    # the K/V stash is a strided view of the fused q/k/v output: same bits from the view
+    qkv = torch.randn(B * N, Lr, 3 * C, generator=g).to(dtype).cuda()
+    m2, sd2 = ops.token_stats(qkv[..., 2 * C:].unsqueeze(1), heads=H)
+    m3, sd3 = ops.token_stats(qkv[..., 2 * C:].contiguous().unsqueeze(1), heads=H)
+    assert torch.equal(m2, m3) and torch.equal(sd2, sd3)
+
+
+def test_zero_filled_reference_keeps_the_style_mean_quirk_through_the_cache():
+    from face_replace.models.attn_processors import register_attention_processor_kv_unet
+    from instantrestore_amd import ops
+    from instantrestore_amd.kv_harvest import get_conditioning_keys_values
+    from instantrestore_amd.unet_host import AttnTopologyUNet
+    import __graft_entry__ as ge
+    from types import SimpleNamespace
+    cfg = SimpleNamespace(use_adain=True, train_input=True, condition_on_face_embeds=False)
+    unet = AttnTopologyUNet(seed=3).to("cuda")
+    ge.register_attention_processor_kv_unet_default(unet, cfg)
+    register_attention_processor_kv_unet(unet)
+    text = torch.randn(4, 77, 1024, device="cuda")
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        keys, vals, stats = get_conditioning_keys_values(unet, torch.randn(4, 4, 16, 16, device="cuda"), None, text, 2, [2, 1],
+                                                         with_stats=True)
+    assert len(stats) == 9
+    for l, (v, st) in enumerate(zip(vals, stats)):
+        B, N, L, C = v.shape
+        H = C // 64
+        assert st[0].shape == (B, N, H, 64) and float(st[0][1, 1].abs().max()) == 0.0 and float(st[1][1, 1].abs().max()) == 0.0
+        vs = torch.randn(B, L, C, device="cuda").to(v.dtype)
+        a0, b0 = ops.adain_stats(vs, v, heads=H)                       # from the zero-filled tensor itself
+        a1, b1 = ops.adain_stats_cached(vs, st[0], st[1], heads=H)     # from the (invalidated) cached statistics
+        assert torch.equal(a0, a1) and torch.equal(b0, b1)
+        mean_s, _ = ops.token_stats(vs.unsqueeze(1), heads=H)
+        assert torch.equal(b1[1, 1], mean_s[1, 0])                     # zeroed reference: b == mean(V_self) exactly
+
+
+def test_shared_processor_output_is_unchanged_by_ref_stats(two_streams=False):
+    import bench
+    dev = torch.device("cuda", 0)
+    layers, (B, N, px, dtype, use_adain) = bench.build_workload("cfg2", True, dev, seed=77)
+    saved = bench._AUTOCAST["dtype"]
+    bench._AUTOCAST["dtype"] = dtype
+    try:
+        with torch.no_grad():
+            bench.REF_STATS["on"] = False
+            ref = [o.clone() for o in bench.hot_path_step(layers, B, N, False, two_streams)]
+            bench.REF_STATS["on"] = True
+            got = bench.hot_path_step(layers, B, N, False, two_streams)
+            torch.cuda.synchronize()
+    finally:
+        bench.REF_STATS["on"] = True
+        bench._AUTOCAST["dtype"] = saved
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)

@@ -1,0 +1,50 @@
+"""same-box interleaved A/B of the bench step: usage _ab_step.py <switch> ; switch in {ref_stats, own_gemm}
+ ref_stats: AdaIN content statistics from the capture layer (round 3) vs re-read in every shared layer
+ own_gemm : this library's GEMMs for every projection vs F.linear for the shapes the vendor GEMM served before round 3"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from instantrestore_amd import attn_processors as ap, ops
+
+what = sys.argv[1] if len(sys.argv) > 1 else "ref_stats"
+dev = torch.device("cuda", 0)
+layers, (B, N, px, dtype, use_adain) = bench.build_workload("cfg2", True, dev, seed=1234)
+bench._AUTOCAST["dtype"] = dtype
+orig_supported = ops.linear_supported
+
+
+def old_rule(x, w, b):   # rounds 1-2: own kernels for K <= 320 / 640 above 2^24 output elements only
+    rows = x.numel() // x.shape[-1]
+    k = w.shape[1]
+    return orig_supported(x, w, b) and ((k % 64 == 0 and k <= 320) or k == 640) and rows * w.shape[0] >= (1 << 24)
+
+
+def setmode(on):
+    if what == "ref_stats":
+        bench.REF_STATS["on"] = on
+    else:
+        ops.linear_supported = orig_supported if on else old_rule
+
+
+def run(two, steps=20):
+    with torch.no_grad():
+        for _ in range(3):
+            bench.hot_path_step(layers, B, N, False, two)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bench.hot_path_step(layers, B, N, False, two)
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+res = {}
+for rnd in range(4):
+    for on in (True, False):
+        setmode(on)
+        for two in (True, False):
+            res.setdefault((on, two), []).append(run(two))
+setmode(True)
+for (on, two), v in sorted(res.items()):
+    print("%s=%-5s %s: %s ms  median %.3f" % (what, on, "two streams" if two else "one stream ", ["%.3f" % x for x in v], sorted(v)[len(v) // 2]))

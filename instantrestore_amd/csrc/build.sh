@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${IR_OUT:-${HERE}/../libinstantrestore_hip.so}"
 BUILD_DIR="${IR_BUILD_DIR:-build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=(linear_tiled.hip shared_attn_fwd.hip shared_attn_fwd_pipe.hip shared_attn_fwd_pp.hip shared_attn_fwd_w64.hip shared_attn_fwd_sp.hip shared_attn_fwd_tp.hip attn_probs.hip adain.hip image_io.hip linear_skinny.hip c_abi.hip)
+SRCS=(linear_tiled.hip shared_attn_fwd.hip shared_attn_fwd_pipe.hip shared_attn_fwd_w64.hip attn_probs.hip adain.hip image_io.hip linear_skinny.hip c_abi.hip)
 cd "${HERE}"
 OBJS=()
 pids=()
@@ -16,7 +16,7 @@ for s in "${SRCS[@]}"; do
   OBJS+=("$o")
   extra=()
   # the 64-row kernels need scalar (single-issue) fp32 code where the SLP vectoriser would form v_pk_* operations
-  [[ "$s" == shared_attn_fwd_w64.hip || "$s" == shared_attn_fwd_sp.hip || "$s" == shared_attn_fwd_tp.hip ]] && extra+=(-fno-slp-vectorize)
+  [[ "$s" == shared_attn_fwd_w64.hip ]] && extra+=(-fno-slp-vectorize)
   "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${extra[@]}" "$@" -c "$s" -o "$o" &
   pids+=($!)
 done

@@ -63,7 +63,11 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
       // instead of a separate pass that reads 4 and writes 2 bytes per element ahead of every projection
       // one row block at a time: all 40 fp32 fragments in flight at once would need 320 registers and the allocator
       // answers by spilling resident fragments to scratch (reloaded in the main loop, each reload draining the W stream)
+#ifdef LIN_ABL_L2LOAD   // timing ablation (WRONG results): X rows folded onto the first 1024 - no HBM reads
+      const float* base = (const float*)p.x + hi * 8 - (int64_t)(ra & ~1023) * p.x_ld;
+#else
       const float* base = (const float*)p.x + hi * 8;
+#endif
 #pragma unroll
       for (int ks = 0; ks < 4 * KS; ++ks)
         xA[ks] = __builtin_convertvector(*(const f32x8*)(base + (int64_t)ra * p.x_ld + ks * 16), v8);
@@ -139,7 +143,11 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
     const int r = 8 * j + (lane >> 3);
     const u32x4 v = *(const u32x4*)(tb + r * TPITCH + (lane & 7) * 16);
     const int row = row0 + r;
+#ifdef LIN_ABL_L2STORE   // timing ablation (WRONG results): every store lands in the first 1024 rows of Y - same stream, no HBM writes
+    T* yp = (T*)p.y + (int64_t)((row < p.M ? row : p.M - 1) & 1023) * p.y_ld + n0 + (lane & 7) * 8;
+#else
     T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 7) * 8;
+#endif
     *(u32x4*)yp = v;
   };
   auto store_half = [&](int j, int n0) {   // 16 rows x 64 B (left half of the tile): a range's odd last chunk
@@ -155,14 +163,26 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
   // (a write path running at HBM speed back-pressures the issuing wave: eight stores in a row stall it and its lockstep
   // partner workgroup while the matrix pipe idles); compute chunk i; then wait ONLY for chunk i+1: vector memory
   // operations retire in issue order and the stores were issued after it, so they may stay in flight across the barrier.
+#ifdef LIN_TRACE
+  // development aid: the four waves of workgroup 0 stamp s_memtime at the phase boundaries of chunks 4..19 into the bias
+  // region of LDS (bias-free launches only); dumped into the head of Y at the end (tools/gpu_lin_trace.py)
+#define LT_STAMP(ev) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && i >= 4 && i < 20 && lane == 0) \
+    ((IR_LDS unsigned*)(IR_LDS unsigned char*)sbias)[(wid * 16 + (i - 4)) * 8 + (ev)] = (unsigned)__builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define LT_STAMP(ev) do { } while (0)
+#endif
   f32x16 accA, accB;
   for (int i = 0; i < ncl; ++i) {
     const int c = c_begin + i, cur = i & 1;
+    LT_STAMP(0);
     if (i + 1 < ncl) issue_chunk(c + 1, cur ^ 1);   // its slot was last read in iteration i-1
+    LT_STAMP(1);
     if (i > 0) {
       stage_block(accA, 0, (c - 1) * NCH, (i - 1) & 1);
       stage_block(accB, 32, (c - 1) * NCH, (i - 1) & 1);
     }
+    LT_STAMP(2);
     const bool pair_done = i > 0 && (i & 1) == 0;   // chunks i-2, i-1 are both in the tile
     const unsigned char* Wb = smem + cur * CHUNK_BYTES;
 #pragma unroll
@@ -192,10 +212,19 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    LT_STAMP(3);
     if (pair_done) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    LT_STAMP(4);
     __syncthreads();
   }
+#ifdef LIN_TRACE
+  if (blockIdx.x == 0 && !BIAS) {
+    __syncthreads();
+    for (int j = tid; j < 4 * 16 * 8; j += NT) ((unsigned*)p.y)[j] = ((IR_LDS unsigned*)(IR_LDS unsigned char*)sbias)[j];
+    return;
+  }
+#endif
   if ((ncl & 1) == 0) {   // the last chunk completes a pair (its partner went into the tile in the last iteration)
     stage_block(accA, 0, (c_end - 1) * NCH, 1);
     stage_block(accB, 32, (c_end - 1) * NCH, 1);
@@ -418,7 +447,11 @@ hipError_t launch_skinny2(const LinearKParams& p, int grid, hipStream_t s) {
   // two W chunks + NW staging tiles + the bias of at most N columns: 78 KiB at K = 320 with 4 waves (two workgroups per CU
   // fit while the bias stays under ~2 KiB, i.e. N <= 960; wider biased outputs run one workgroup per CU), 114 KiB with 8
   const size_t fixed = (size_t)2 * KS * SUB_BYTES + (size_t)NW * 64 * kSkinnyTPitch;
+#ifdef LIN_TRACE
+  const size_t dyn = fixed + 4096;
+#else
   const size_t dyn = fixed + (BIAS ? (size_t)p.N * sizeof(T) : 0);
+#endif
   static bool attr_set[64] = {};   // per instantiation and per device; idempotent (see the K = 640 launch below)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
@@ -438,7 +471,11 @@ hipError_t launch_skinny(const LinearKParams& p0, hipStream_t s) {
   // 8-wave (512-row, one per CU) workgroups measured SLOWER than two 4-wave ones per CU on every K = 320 shape of the step
   // (135 vs 119-125 us on 131072 x 960, 52 vs 48 on x 320, 47 vs 44 on 32768 x 960; profiles/r2_kernel_experiments.txt 7):
   // development builds only (-DIR_ABLATIONS -DLIN_NW8_MIN_M=<rows>)
+#if defined(IR_ABLATIONS) && defined(LIN_NW8_MIN_M)
+  const bool w8 = p.M >= LIN_NW8_MIN_M;
+#else
   constexpr bool w8 = false;
+#endif
   const int rows = w8 ? 512 : 256, slots = w8 ? 256 : 512;
   const int mblocks = (p.M + rows - 1) / rows;
   const int nchunks = p.N / NCH;
@@ -448,6 +485,9 @@ hipError_t launch_skinny(const LinearKParams& p0, hipStream_t s) {
   if (nsplit < 1) nsplit = 1;
   p.nsplit = nsplit;
   const int grid = mblocks * nsplit;
+#if defined(IR_ABLATIONS) && defined(LIN_NW8_MIN_M)
+  if (w8) return p.bias != nullptr ? launch_skinny2<T, KS, true, 8>(p, grid, s) : launch_skinny2<T, KS, false, 8>(p, grid, s);
+#endif
   return p.bias != nullptr ? launch_skinny2<T, KS, true, 4>(p, grid, s) : launch_skinny2<T, KS, false, 4>(p, grid, s);
 }
 

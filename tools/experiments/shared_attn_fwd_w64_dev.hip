@@ -31,13 +31,20 @@ struct RowBlock {
 //   acc' <- acc' * (a_cur / a_next) + l_cur * (b_cur / a_next)        (a = 1, b = 0 for the self segment)
 // and at the end a_next = 1 turns the frame into the true total.  a = (sigma_style + eps) /
 // (sigma_content + eps) is strictly positive; the lazy-max rescale is linear and touches acc' as before.
+// PP ("ping-pong", 8 waves): the loop is rotated to { PV(t-1), QK^T(t) | barrier | softmax(t) | barrier } and waves
+// 4-7 run ONE PHASE behind waves 0-3 (one extra barrier at their start, one at the others' end), so on every SIMD
+// one wave is in its vector phase while the other is in its matrix phase - with a single barrier per tile both
+// waves of a SIMD sit in the same phase and matrix and vector time simply add up (tools/ubench/pingpong2.hip:
+// 2080 -> 1650 ns per tile pair for this instruction mix).  K/V ring of 4 pairs: pair u is read in phases
+// 2u .. 2u+3 (K(u) by QK^T(u) in M(u), V(u) by PV(u) in M(u+1), each phase twice: once per wave group); every
+// wave issues its share of pair j+2 at the start of its M(j) and waits for pair j+1 at the end of it.
 // QS (IR_FLAG_Q_PRESCALED, 8 waves): Q arrives as Q * scale * log2(e) (the fused q/k/v projection folds the factor into
 // its weights), so the scores leave the matrix pipe as exponents; the running reference enters through the C operand of
 // the first QK^T MFMAs of a tile (a 16-register block per row block, rewritten only when the lazy rule moves the
 // reference) and the scale-and-subtract multiply-add per score disappears (64 of ~236 VALU instructions per wave and
 // tile).  The two reference blocks take the registers of the Q fragments, which move to a wave-private LDS copy and
-// are read per tile next to the K fragments.
-template <typename T, bool FOLD, int NW = 4, bool QS = false>
+// are read per tile next to the K fragments (the arrangement of the ping-pong build).
+template <typename T, bool FOLD, int NW = 4, bool PP = false, bool QS = false>
 __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
@@ -49,9 +56,11 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #ifndef W64_RING
 #define W64_RING 2
 #endif
-  constexpr int RING = W64_RING;
+  constexpr int RING = PP ? 4 : W64_RING;
   constexpr int K_OFF = 0, V_OFF = RING * TILE_BYTES;
-  constexpr bool QLDS = QS;   // Q fragments live in a wave-private LDS copy: ring + NW * 8 KiB exceed the static limit
+  // PP: the ring (64 KiB) and a wave-private copy of the Q fragments (8 KiB per wave; the rotated loop keeps the
+  // next tile's scores alive across the iteration and has no registers left for them) exceed the static limit
+  constexpr bool QLDS = PP || QS;   // Q fragments live in LDS: ring + NW * 8 KiB exceed the static limit
   __shared__ __attribute__((aligned(16))) unsigned char smem_static[QLDS ? 16 : 2 * RING * TILE_BYTES];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
   unsigned char* const smem = QLDS ? smem_dyn : smem_static;
@@ -87,6 +96,9 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   const int bh = lin / p.nqb, qb = lin - bh * p.nqb;
   const int b = bh / p.H, h = bh - b * p.H;
 
+#ifdef W64_TRACE
+  const unsigned long long tr_c0 = __builtin_readcyclecounter(), tr_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- Q fragments of both row blocks -----------------------------------------------------------
   const int qrowA = qb * QB + wid * 64 + lq, qrowB = qrowA + 32;
   v8 qA[4], qB[4];
@@ -247,15 +259,36 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     const float mc = R.m_run * c2;
     const f32x2 cc = {c2, c2};
     const f32x2 nm = {-mc, -mc};
-    {
+    if (PP) {
+      // single-issue forms only: packed fp32 operations share the matrix pipe's datapath and do not make
+      // progress while the other wave of the SIMD has MFMAs in flight (tools/ubench/overlap_types.hip: 6-14 %
+      // overlap against 71-97 % for v_fma_f32 / v_exp_f32 / v_cvt_pk / v_max3).  Plain scalar code: this file is
+      // built with -fno-slp-vectorize (build.sh) so that it stays scalar, and the compiler's hazard recogniser
+      // still sees the v_exp -> VALU dependency (it cannot look inside inline asm).
+      float la0 = R.la[0], la1 = R.la[1], lb0 = R.lb[0], lb1 = R.lb[1];
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float x0 = fast_exp2(__builtin_fmaf(s0[r], c2, -mc));
+        const float x1 = fast_exp2(__builtin_fmaf(s0[r + 1], c2, -mc));
+        const float y0 = fast_exp2(__builtin_fmaf(s1[r], c2, -mc));
+        const float y1 = fast_exp2(__builtin_fmaf(s1[r + 1], c2, -mc));
+        la0 += x0; la1 += x1; lb0 += y0; lb1 += y1;
+        s0[r] = x0; s0[r + 1] = x1;
+        s1[r] = y0; s1[r + 1] = y1;
+      }
+      R.la = f32x2{la0, la1};
+      R.lb = f32x2{lb0, lb1};
+    } else {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
       f32x2 t0v = {s0[r], s0[r + 1]};
       f32x2 t1v = {s1[r], s1[r + 1]};
       t0v = __builtin_elementwise_fma(t0v, cc, nm);
       t1v = __builtin_elementwise_fma(t1v, cc, nm);
+#ifndef W64_ABL_NOEXP   // timing ablation only (WRONG results): what do the 64 v_exp_f32 per wave and tile cost?
       t0v[0] = fast_exp2(t0v[0]); t0v[1] = fast_exp2(t0v[1]);
       t1v[0] = fast_exp2(t1v[0]); t1v[1] = fast_exp2(t1v[1]);
+#endif
       R.la += t0v;
       R.lb += t1v;
       s0[r] = t0v[0]; s0[r + 1] = t0v[1];
@@ -270,7 +303,11 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   };
 
   auto softmax = [&](RowBlock& R, f32x16& s0, f32x16& s1, v8 (&pk)[2][2], int valid, bool force = false) {
+#ifdef W64_ABL_NOMAX   // timing ablation (right only while no later tile moves the reference): no row max after the first tile
+    const float mx = force ? row_max(s0, s1, valid) : 0.f;
+#else
     const float mx = row_max(s0, s1, valid);
+#endif
     softmax_rest(R, s0, s1, pk, mx, force);
   };
 
@@ -320,7 +357,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #pragma unroll
   for (int c = 0; c < CH; ++c) { kvo[c] += (unsigned)(t0 * kstep); vvo[c] += (unsigned)(t0 * vstep); }
   issue_pair(0);
-  if (RING == 3 && NTILES > 1) issue_pair(1);
+  if ((RING == 3 || PP) && NTILES > 1) issue_pair(1);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qA[ks]), "v"(qB[ks]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -352,8 +389,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         if (ks < 3) {
           kn0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks + 1]);
           kn1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks + 1]);
+#ifndef W64_ABL_QREUSE   // timing ablation (WRONG results): what do three quarters of the Q fragment reads cost?
           qan = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (ks + 1) * 1024);
           qbn = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + ks + 1) * 1024);
+#endif
         }
         if (QLDS) __builtin_amdgcn_sched_barrier(0);
         if (QS && ks == 0) {
@@ -411,18 +450,95 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     }
   };
 
-  {
+#ifdef W64_PP_TRACE
+  // development aid: waves 0 and 4 of workgroup 0 stamp s_memtime at the phase boundaries of tiles 8..23 into the
+  // head of the LSE buffer (rows of a whole item: the combine kernel does not write there) (the normal LSE stores are compiled out in this build)
+#define PP_STAMP(ev) do { if (blockIdx.x == 0 && (wid == 0 || wid == 4) && t >= 8 && t < 24 && lane == 0 && p.lse != nullptr) \
+    p.lse[((wid >> 2) * 16 + (t - 8)) * 8 + (ev)] = __uint_as_float((unsigned)__builtin_readcyclecounter()); } while (0)
+#else
+#define PP_STAMP(ev) do { } while (0)
+#endif
+  if (PP) {
+    // Phases of a wave: M(0) V(0) M(1) V(1) ... V(NT-1) M(NT), a barrier after each;  M(t) = PV(t-1), QK^T(t) and
+    // V(t) = softmax(t).  The scores live inside one iteration, the probabilities are carried to the next.
+    const int grp = wid >> 2;
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one phase behind
+    v8 pkA[2][2], pkB[2][2];
+    int cur = 0, prev = 3;
+    auto close_tile = [&](bool has_next) {
+      if (++ct0 == c_ntile) {
+        if (FOLD) fold_boundary(cseg, has_next);
+        ct0 = 0; ++cseg; c_ntile = p.tiles_ref; c_len = p.Lr;
+      }
+    };
+    for (int t = 0; t < NTILES; ++t) {
+      // ---- matrix phase ----------------------------------------------------------------------------
+      PP_STAMP(0);
+      __builtin_amdgcn_s_setprio(3);   // the matrix phase wins the issue port: both phases then take the same time (tools/gpu_pp_trace.py)
+      const bool more = t + 2 < NTILES;
+      if (more) issue_pair(cur >= 2 ? cur - 2 : cur + 2);   // pair t+2 -> the slot pair t-2 left two barriers ago
+      if (t > 0) {
+        pv_tile(smem + V_OFF + prev * TILE_BYTES, pkA, pkB);
+        close_tile(true);
+      }
+      PP_STAMP(1);
+      __builtin_amdgcn_sched_barrier(0);   // the score accumulators must not come alive under PV
+      f32x16 sa0, sa1, sb0, sb1;
+      qk_tile(smem + K_OFF + cur * TILE_BYTES, sa0, sa1, sb0, sb1);
+      // pair t+1 has landed (vector memory operations retire in issue order; only pair t+2 may stay in flight)
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_STAMP(2);
+      __builtin_amdgcn_s_barrier();
+      PP_STAMP(3);
+      __builtin_amdgcn_s_setprio(0);
+      // ---- vector phase (row max included: moved into the matrix phase it lengthens the critical wave by more
+      //      than it saves here - tools/gpu_pp_trace.py) -----------------------------------------------------
+      const int valid = c_len - ct0 * KVB;
+      softmax(A, sa0, sa1, pkA, valid);
+      softmax(Bk, sb0, sb1, pkB, valid);
+      // the probabilities are used in the NEXT phase only: without these pins hipcc sinks the exp / convert half of
+      // the softmax and the row-sum additions below the barrier, i.e. into the matrix phase
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(pkA[i][j]), "+v"(pkB[i][j]));
+      asm volatile("" : "+v"(A.la), "+v"(A.lb), "+v"(Bk.la), "+v"(Bk.lb));   // the row sums too (next use: segment end)
+      __builtin_amdgcn_sched_barrier(0);
+      PP_STAMP(4);
+      __builtin_amdgcn_s_barrier();
+      PP_STAMP(5);
+      prev = cur;
+      cur = (cur == 3) ? 0 : cur + 1;
+    }
+    pv_tile(smem + V_OFF + prev * TILE_BYTES, pkA, pkB);
+    close_tile(false);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
+#ifdef W64_TRACE
+  // development aid: every wave of workgroup 0 stamps s_memtime at the phase boundaries of tiles 8..23 into LDS
+  // (behind the ring and the Q copies; the launcher adds 4 KiB), dumped into the head of the LSE buffer at the end
+#define TR_STAMP(ev) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && t >= 8 && t < 24 && lane == 0) \
+    *(IR_LDS unsigned*)(IR_LDS unsigned char*)(smem + Q_OFF + NW * 8192 + ((wid * 16 + (t - 8)) * 8 + (ev)) * 4) = (unsigned)__builtin_readcyclecounter(); \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TR_STAMP(ev) do { } while (0)
+#endif
   int cur = 0;
   for (int t = 0; t < NTILES; ++t) {
+    TR_STAMP(0);
     // pair t+RING-1 goes into the slot that was last read in step t-1
     if (t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
+    TR_STAMP(1);
 
     const unsigned char* Kb = smem + K_OFF + cur * TILE_BYTES;
     f32x16 sa0, sa1, sb0, sb1;
     qk_tile(Kb, sa0, sa1, sb0, sb1);
+    TR_STAMP(2);
 
     const int valid = c_len - ct0 * KVB;
     v8 pkA[2][2], pkB[2][2];
+#ifndef W64_QS_EXACTMAX
     if (QS) {
       // Reference checked AFTER the exponentials: the scores are exponents relative to the running reference
       // already, so P = exp2(S) needs no row max; what has to be caught is a tile that outgrows the reference, and the
@@ -474,8 +590,14 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       };
       if (valid < KVB) { mask(sa0, sa1); mask(sb0, sb1); }
       float tsA[4], tsB[4];
+#ifdef W64_ABL_NOSM   // timing ablation (WRONG results): no exponentials, no row sums - the matrix skeleton with the packing
+      tsA[0] = tsA[1] = tsA[2] = tsA[3] = tsB[0] = tsB[1] = tsB[2] = tsB[3] = 1.f;
+      pack(sa0, sa1, pkA);
+      pack(sb0, sb1, pkB);
+#else
       exp_sum(sa0, sa1, tsA, pkA);
       exp_sum(sb0, sb1, tsB, pkB);
+#endif
       const float big = max3(max3(tsA[0], tsA[1], tsA[2]), max3(tsB[0], tsB[1], tsB[2]), max3(tsA[3], tsB[3], tsB[3]));
       if (t == 0 || __any(!(big <= 2048.f))) {
         qk_tile(Kb, sa0, sa1, sb0, sb1);
@@ -486,12 +608,14 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       A.la[0] += tsA[0]; A.la[1] += tsA[1]; A.lb[0] += tsA[2]; A.lb[1] += tsA[3];
       Bk.la[0] += tsB[0]; Bk.la[1] += tsB[1]; Bk.lb[0] += tsB[2]; Bk.lb[1] += tsB[3];
     } else
+#endif
     {
     softmax(A, sa0, sa1, pkA, valid, QS && t == 0);
     softmax(Bk, sb0, sb1, pkB, valid, QS && t == 0);
     }
 
     pv_tile(smem + V_OFF + cur * TILE_BYTES, pkA, pkB);
+    TR_STAMP(3);
     if (++ct0 == c_ntile) {
       if (FOLD) fold_boundary(cseg, t + 1 < NTILES);
       const KArgs c = cold();
@@ -502,9 +626,24 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     // (vector memory operations retire in issue order and nothing else was issued after them)
     if (RING == 3 && t + 2 < NTILES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TR_STAMP(4);
+#ifndef W64_ABL_NOBAR   // timing ablation (racy, WRONG results): what does the per-tile barrier cost?
     __syncthreads();
+#endif
     cur = (RING == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
   }
+#ifdef W64_TRACE
+  if (QLDS && blockIdx.x == 0 && p.lse != nullptr) {
+    __syncthreads();
+    for (int i = tid; i < NW * 16 * 8; i += NT)
+      p.lse[i] = __uint_as_float(*(IR_LDS unsigned*)(IR_LDS unsigned char*)(smem + Q_OFF + NW * 8192 + i * 4));
+    if (tid == 0) {   // shader cycles and 100 MHz ticks of this workgroup's main loop: the clock it ran at
+      p.lse[1024] = __uint_as_float((unsigned)(__builtin_readcyclecounter() - tr_c0));
+      p.lse[1025] = __uint_as_float((unsigned)(__builtin_amdgcn_s_memrealtime() - tr_r0));
+      p.lse[1026] = __uint_as_float((unsigned)NTILES);
+    }
+  }
+#endif
   }
 
   // ---- epilogue (per row block) ---------------------------------------------------------------------
@@ -554,15 +693,17 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
           *(v4*)(op + 32 + 8 * g4 + 4 * hi) = __builtin_convertvector(x1, v4);
         }
       }
+#if !defined(W64_PP_TRACE) && !defined(W64_TRACE)
       if (p.lse != nullptr && hi == 0)
         p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_raw * p.scale + __logf(l_fin);
+#endif
     }
   };
   finish(A, qrowA, 0);
   finish(Bk, qrowB, 32);
 }
 
-template <typename T, bool FOLD, int NW = 4, bool QS = false>
+template <typename T, bool FOLD, int NW = 4, bool PP = false, bool QS = false>
 hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   AttnKParams p = p0;
   constexpr int QB = NW * 64;
@@ -584,19 +725,25 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.ws_ml = p.ws + (size_t)8 * rem * k * QB * 64;
   const int grid = 8 * (full + rem * k);
   size_t dyn_lds = 0;
-  if (QS) {
-    dyn_lds = (size_t)2 * W64_RING * TILE_BYTES + (size_t)NW * 8192;   // K/V ring + the waves' Q fragments
+  if (PP || QS) {
+    dyn_lds = (size_t)2 * (PP ? 4 : W64_RING) * TILE_BYTES + (size_t)NW * 8192;   // K/V ring + the waves' Q fragments
+#ifdef W64_TRACE
+    dyn_lds += 4096;
+#endif
+#ifdef W64_SOLO   // development aid: one 4-wave workgroup per CU = one wave per SIMD
+    dyn_lds += 48 * 1024;
+#endif
     static bool attr_set[64] = {};   // per instantiation and per device; idempotent, so a race only repeats the call
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
     if (!attr_set[dev]) {
-      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, QS>,
+      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, PP, QS>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
       if (ea != hipSuccess) return ea;
       attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, QS>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
+  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, PP, QS>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || k <= 1) return e;
   return ir_launch_shared_attn_combine(p, std::is_same<T, __bf16>::value ? 1 : 0, QB, rem, s);
@@ -604,17 +751,27 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
 
 }  // namespace
 
+template <bool PP>
 static hipError_t launch_x8(const AttnKParams& p, int dtype, hipStream_t s) {
-  if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8>(p, s) : launch<_Float16, true, 8>(p, s);
-  return dtype == 1 ? launch<__bf16, false, 8>(p, s) : launch<_Float16, false, 8>(p, s);
+  if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8, PP>(p, s) : launch<_Float16, true, 8, PP>(p, s);
+  return dtype == 1 ? launch<__bf16, false, 8, PP>(p, s) : launch<_Float16, false, 8, PP>(p, s);
 }
 
+#ifdef IR_ABLATIONS   // variant 15 (rotated phases, wave groups one phase apart): development builds only
+hipError_t ir_launch_shared_attn_fwd_w64x8_pp(const AttnKParams& p, int dtype, hipStream_t s) {  // ping-pong wave groups
+  return launch_x8<true>(p, dtype, s);
+}
+#endif
+
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s) {  // 8-wave (512-row) workgroups
+#ifdef W64_SOLO
+  if (p.q_prescaled) return dtype == 1 ? launch<__bf16, false, 4, false, true>(p, s) : launch<_Float16, false, 4, false, true>(p, s);
+#endif
   if (p.q_prescaled) {   // IR_FLAG_Q_PRESCALED: the QS instantiation
-    if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8, true>(p, s) : launch<_Float16, true, 8, true>(p, s);
-    return dtype == 1 ? launch<__bf16, false, 8, true>(p, s) : launch<_Float16, false, 8, true>(p, s);
+    if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8, false, true>(p, s) : launch<_Float16, true, 8, false, true>(p, s);
+    return dtype == 1 ? launch<__bf16, false, 8, false, true>(p, s) : launch<_Float16, false, 8, false, true>(p, s);
   }
-  return launch_x8(p, dtype, s);
+  return launch_x8<false>(p, dtype, s);
 }
 
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s) {

@@ -27,7 +27,7 @@ struct AttnKParams {
   int64_t o_sb, o_sl, o_sh;
   int B, H, Lq, Ls, N, Lr;
   int include_self;   // 0/1
-  int q_prescaled;    // IR_FLAG_Q_PRESCALED: q holds Q * scale * log2(e)   (shared_attn_fwd_sp.hip only)
+  int q_prescaled;    // IR_FLAG_Q_PRESCALED: q holds Q * scale * log2(e)   (the 64-row kernel's QS instantiation, the 32-row kernel's PRESC forms)
   int out_f32;        // IR_FLAG_OUT_F32: fp32 output, o_s* in fp32 elements (every product kernel + combine)
   int tiles_self;     // ceil(Ls/64) if include_self else 0
   int tiles_ref;      // ceil(Lr/64)

@@ -406,21 +406,20 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 }  // namespace
 #endif  // IR_ABLATIONS
 
-// variant & 15 selects the kernel (per-call tuning field of ir_shared_attn_args; 0 = default dispatch, see
-// ir_attn_default_kernel).  Product library:
-//   17 (IR_TUNE_TP32) 32 rows per wave, two waves per SIMD, three-stage pipeline with a spelled-out interleave
-//      (shared_attn_fwd_tp.hip)
-//   16 (IR_TUNE_SP) one wave per SIMD, 64 query rows per wave, software-pipelined (shared_attn_fwd_sp.hip)
+// variant & 31 selects the kernel (per-call tuning field of ir_shared_attn_args; 0 = default dispatch, see
+// ir_attn_default_is_w64).  Product library:
 //   13 64 query rows per wave, 8-wave (512-row) workgroups (shared_attn_fwd_w64.hip)     12 the same, 4 waves
 //   10 software-pipelined 32-row kernel, 4 waves, asm-issued LDS-DMA staging, lazy max (shared_attn_fwd_pipe.hip)
 //    7 the same with an exact (every-change) rescale
 //   11 10 + pre-scaled Q, reference through the MFMA C operand (opt-in fast mode: one more rounding of Q)
 //   14 10 with the next tile's QK^T issued before the row max
 //   18 11 with the reference checked after the exponentials (no row max on ordinary tiles; K ring of 3)
-// Development builds only (-DIR_ABLATIONS; documented experiments): 1/2 this file's straight-line
-// kernel with 8 / 4 waves, 3/4 pipelined with register staging, 6 pipelined + builtin LDS-DMA, 8 ping-pong wave
-// groups (shared_attn_fwd_pp.hip), 9 straight schedule at 3 waves/SIMD, 15 the 64-row kernel with rotated phases;
-// variant >> 5: ablation bits (timing experiments, WRONG results).
+// Development builds only (tools/experiments/build.sh, -DIR_ABLATIONS; documented experiments, NOTES.md): 1/2 this file's
+// straight-line kernel with 8 / 4 waves, 3/4 pipelined with register staging, 6 pipelined + builtin LDS-DMA, 8 ping-pong
+// wave groups (shared_attn_fwd_pp.hip), 9 straight schedule at 3 waves/SIMD, 15 the 64-row kernel with rotated phases,
+// 16 (IR_TUNE_SP64) one wave per SIMD with a spelled-out interleave, 17 (IR_TUNE_TP32) three-stage 32-row pipeline;
+// variant >> 5: ablation bits (timing experiments, WRONG results).  Those variants write 16-bit results only: they are
+// rejected together with IR_FLAG_OUT_F32.
 bool ir_attn_variant_available(int variant) {
   const int base = variant & 31;
 #ifdef IR_ABLATIONS
@@ -431,8 +430,8 @@ bool ir_attn_variant_available(int variant) {
 #endif
 }
 
-// Default dispatch: on long K/V walks with enough (b, h, 256-row) items to fill the chip, the software-pipelined
-// one-wave-per-SIMD kernel; the 64-rows-per-wave kernel in 512-row workgroups when only that fills it ...
+// Default dispatch: the 64-rows-per-wave kernel in 512-row workgroups for query axes of >= 4096 rows whose (b, h, 512-row)
+// items fill the chip or whose K/V walk is long; the 32-row pipelined kernel below that
 bool ir_attn_default_is_w64(const AttnKParams& p) {
   const long items512 = (long)p.B * p.H * ((p.Lq + 511) / 512);
   return p.Lq >= 4096 && (items512 >= 256 || p.ntiles >= 128);
@@ -441,6 +440,10 @@ bool ir_attn_default_is_w64(const AttnKParams& p) {
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
   if (!ir_attn_variant_available(variant)) return hipErrorInvalidValue;
 #ifdef IR_ABLATIONS
+  {   // the experiments that never learned IR_FLAG_OUT_F32 would write 16-bit data into an fp32 buffer
+    const int b0 = variant & 31;
+    if (p.out_f32 && (b0 == 1 || b0 == 2 || b0 == 8 || b0 == 15 || (variant >> 5) != 0)) return hipErrorInvalidValue;
+  }
   const int abl = variant >> 5;
   if (abl != 0 && (variant & 31) == 3) return ir_launch_shared_attn_fwd_pipe_abl(p, abl, s);
   if (abl != 0) {

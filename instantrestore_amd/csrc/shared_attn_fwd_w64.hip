@@ -426,8 +426,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     if (QS) {
       // Reference checked AFTER the exponentials: the scores are exponents relative to the running reference
       // already, so P = exp2(S) needs no row max; what has to be caught is a tile that outgrows the reference, and the
-      // tile's own row sums (needed anyway) show that: a lane's 32 probabilities sum to more than 2^11 only if one
-      // of them exceeds 2^6 - the lazy rule's bound - and to inf/NaN if one overflowed.  Then (rare; always on the
+      // tile's own row sums (needed anyway) show that: each of a lane's four 8-element partial sums per row block is
+      // compared with 2^11, so no probability above 2^11 gets through (one above 2^8 only beside smaller ones) - harmless
+      // in the 16-bit operands (bf16 range; fp16 max 65504) and the fp32 accumulators; looser than the 2^6 of the lazy
+      // row-max rule of the other kernels, tests/test_gpu_round2.py "mid_jump" pins it - and inf/NaN if one overflowed.  Then (rare; always on the
       // first tile, whose reference is still 0) the scores are formed again - the K tile is still in LDS - and the
       // exact path runs: row max, reference moved, accumulators and sums rescaled.  Saves the 38 v_max3 of every tile.
       auto mask = [&](f32x16& s0, f32x16& s1) {

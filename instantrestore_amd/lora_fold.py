@@ -139,10 +139,15 @@ def invalidate_all(module: nn.Module) -> int:
     return n
 
 
-def install_invalidation_hook(module: nn.Module) -> None:
-    """``load_state_dict`` on ``module`` (checkpoint load, test.py:47-50) drops every cached folded weight below it"""
-    if getattr(module, "_ir_invalidation_hook", None) is None and hasattr(module, "register_load_state_dict_post_hook"):
-        def _hook(mod, incompatible_keys):   # a post hook must return None (torch asserts it)
-            invalidate_all(mod)
+def _invalidate_after_load(mod, incompatible_keys) -> None:
+    """``load_state_dict`` post hook (module-level, so a UNet carrying it still pickles: ``torch.save(unet)``,
+    multiprocessing spawn); a post hook must return None (torch asserts it)"""
+    invalidate_all(mod)
 
-        module._ir_invalidation_hook = module.register_load_state_dict_post_hook(_hook)
+
+def install_invalidation_hook(module: nn.Module) -> None:
+    """``load_state_dict`` on ``module`` (checkpoint load, test.py:47-50) drops every cached folded weight below it.
+    Only a flag is kept on the module (the ``RemovableHandle`` holds weak references that do not pickle)."""
+    if not getattr(module, "_ir_invalidation_hook", False) and hasattr(module, "register_load_state_dict_post_hook"):
+        module.register_load_state_dict_post_hook(_invalidate_after_load)
+        module._ir_invalidation_hook = True

@@ -304,3 +304,18 @@ def test_kv_cache_entries_are_compact_copies():
     assert cache.nbytes("a") == 2 * 3 * 10 * 64 * 4
     cache.get_or_compute("b", lambda: ([k], [v])); cache.get_or_compute("c", lambda: ([k], [v]))
     assert "a" not in cache and len(cache) == 2                           # LRU eviction
+
+
+def test_registered_unet_still_pickles():
+    """the load_state_dict post hook installed by the registration functions is a module-level function and the
+    module keeps a flag, not the RemovableHandle - ``torch.save(unet)`` / multiprocessing spawn keep working"""
+    import io
+    from types import SimpleNamespace
+    from instantrestore_amd.attn_processors import register_attention_processor
+    from instantrestore_amd.unet_host import AttnTopologyUNet
+    u = AttnTopologyUNet(block_out_channels=(64, 128, 128, 128), attention_head_dim=(1, 2, 2, 2), cross_attention_dim=64, seed=1)
+    register_attention_processor(u, SimpleNamespace(use_adain=True, train_input=True, condition_on_face_embeds=False))
+    buf = io.BytesIO()
+    torch.save(u, buf)
+    assert buf.tell() > 0
+    u.load_state_dict(u.state_dict())      # the hook still fires and returns None

@@ -490,15 +490,28 @@ def extra_scatter_gather(B_local, N, px, world, rank, dev, backend):
         time.sleep(1e6)
     total = B_local * world
     dt = torch.float16
-    if backend != "nccl" and world > 1:
-        tdev = torch.device("cpu")
-    else:
-        tdev = dev
-    deg = torch.zeros(total, 3, px, px, dtype=dt, device=tdev) if rank == 0 else None
-    refs = torch.zeros(total, N, 3, px, px, dtype=dt, device=tdev) if rank == 0 else None
     step = lambda d, r: d * 1.0    # stands for the restoration of the shard: (b,3,px,px) -> (b,3,px,px)
+    if backend != "nccl" and world > 1:
+        # control-flow test hook (gloo, CPU tensors): the HIP image kernels have no CPU fallback, so the transfers carry
+        # pre-normalised fp16 tensors both ways (the round-2 form of this leg)
+        tdev = torch.device("cpu")
+        deg = torch.zeros(total, 3, px, px, dtype=dt, device=tdev) if rank == 0 else None
+        refs = torch.zeros(total, N, 3, px, px, dtype=dt, device=tdev) if rank == 0 else None
+        run = lambda: sharding.run_sharded(step, deg, refs, total, (3, px, px), N, dt, tdev)
+        want_shape, path = (total, 3, px, px), "fp16 tensors both ways (CPU test hook)"
+        nbytes = (1 + N) * 3 * px * px * 2 + 3 * px * px * 2
+    else:
+        # the image kernels fused with the shard buffers: raw uint8 images -> Lanczos preprocess writes
+        # the identity-major send buffer -> one transfer per peer -> step -> tensor2im on every rank -> uint8 pixels back
+        tdev = dev
+        g = torch.Generator().manual_seed(7)
+        images = [[torch.randint(0, 256, (px, px, 3), generator=g, dtype=torch.uint8).to(dev) for _ in range(1 + N)]
+                  for _ in range(total)] if rank == 0 else None
+        run = lambda: sharding.run_sharded_images(step, images, total, N, px, dt, tdev)
+        want_shape, path = (total, px, px, 3), "uint8 images in, Lanczos preprocess into the send buffers, uint8 pixels back"
+        nbytes = (1 + N) * 3 * px * px * 2 + 3 * px * px
     for _ in range(2):
-        sharding.run_sharded(step, deg, refs, total, (3, px, px), N, dt, tdev)
+        run()
     if tdev.type == "cuda":
         torch.cuda.synchronize()
     if world > 1:
@@ -506,16 +519,16 @@ def extra_scatter_gather(B_local, N, px, world, rank, dev, backend):
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        out = sharding.run_sharded(step, deg, refs, total, (3, px, px), N, dt, tdev)
+        out = run()
     if tdev.type == "cuda":
         torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    ok = (out is not None and tuple(out.shape) == (total, 3, px, px)) if rank == 0 else out is None or world == 1
+    ok = (out is not None and tuple(out.shape) == want_shape) if rank == 0 else out is None or world == 1
     return {"scatter_gather_ms": round(ms, 3), "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
-            "backend": backend if world > 1 else "none (one rank: slicing only)",
-            "bytes_per_identity": (1 + N) * 3 * px * px * 2 + 3 * px * px * 2, "ok": bool(ok)}
+            "backend": backend if world > 1 else "none (one rank: slicing only)", "path": path,
+            "bytes_per_identity_on_the_links": nbytes, "ok": bool(ok)}
 
 
 def _guarded(fn, dev, seconds):

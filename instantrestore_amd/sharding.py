@@ -56,8 +56,8 @@ def scatter_identities(full: Optional[torch.Tensor], total: int, tail_shape: Seq
                 continue
             rlo, rhi = shard_range(total, world, r)
             if rhi > rlo:
-                piece = full[rlo:rhi].contiguous()
-                keep.append(piece)
+                piece = full[rlo:rhi].contiguous()   # a leading-axis slice of a contiguous batch IS contiguous: no copy,
+                keep.append(piece)                   # the producer's output buffer is the send buffer
                 ops.append(dist.P2POp(dist.isend, piece, r, group))
         mine = full[lo:hi].clone()
     else:
@@ -103,3 +103,39 @@ def run_sharded(step_fn, degraded: Optional[torch.Tensor], refs: Optional[torch.
     r = scatter_identities(refs, total, (n_refs, *img_shape), dtype, device, 0, group)
     out = step_fn(d, r)
     return gather_identities(out, total, 0, group)
+
+
+def run_sharded_images(step_fn, images, total: int, n_refs: int, size: int, dtype: torch.dtype, device: torch.device,
+                       preprocess=None, to_image=None, group=None):
+    """The caller's whole per-batch data path with the image kernels fused into the shard transfers:
+
+    rank 0 holds ``images``: ``total`` identities, each a sequence of ``1 + n_refs`` ``uint8`` ``(H, W, 3)`` tensors
+    (degraded image first, then its references; ragged sizes allowed).  ``preprocess`` (default
+    :class:`instantrestore_amd.preprocess.LanczosPreprocessor` - Pillow-exact resize, crop, normalise, cast on the
+    device) is launched ONCE over the identity-major flat list and writes ``(total, 1 + n_refs, 3, size, size)``: an
+    identity's degraded image and references are adjacent, so every peer's shard is ONE contiguous slice of that output -
+    the kernel's output buffer is the send buffer, one transfer per peer (the two-tensor form sends two).  Every rank runs
+    ``step_fn(degraded (b, 3, S, S), refs (b, N, 3, S, S)) -> (b, 3, S, S)`` on its shard and ``to_image`` (default
+    ``ops.tensor2im_u8``: the reference's ``tensor2im``, vis_utils.py:14-23, on the device) BEFORE the gather, so ``uint8``
+    ``(b, S, S, 3)`` pixels travel back - a third of the fp16 tensor's bytes.  Rank 0 returns ``(total, S, S, 3)`` uint8,
+    the others ``None``.  ``preprocess`` / ``to_image`` are injectable for the CPU (gloo) tests: the HIP ones have no CPU
+    fallback."""
+    world, rank = _world(group)
+    if preprocess is None:
+        from .preprocess import LanczosPreprocessor
+        preprocess = LanczosPreprocessor(size, dtype)
+    if to_image is None:
+        from . import ops as _ops
+        to_image = _ops.tensor2im_u8
+    packed = None
+    if rank == 0:
+        if images is None or len(images) != total or any(len(ident) != 1 + n_refs for ident in images):
+            raise ValueError("rank 0 must pass `total` identities of 1 + n_refs images each")
+        flat = [im for ident in images for im in ident]                  # identity-major: shards are contiguous
+        packed = preprocess(flat).view(total, 1 + n_refs, 3, size, size)
+    shard = scatter_identities(packed, total, (1 + n_refs, 3, size, size), dtype, device, 0, group)
+    out = step_fn(shard[:, 0], shard[:, 1:])
+    pixels = to_image(out)                                               # (b, S, S, 3) uint8
+    if pixels.dtype != torch.uint8:
+        raise TypeError("to_image must return uint8 pixels")
+    return gather_identities(pixels, total, 0, group)

@@ -138,3 +138,19 @@ def test_preprocess_properties_constant_and_saturated_images():
     for i, val in enumerate((0, 255, 128, 37)):
         assert torch.equal(out[i], torch.full((3, 512, 512), float(lut[val]))), val
     assert float(out[0].max()) == -1.0 and float(out[1].min()) == 1.0
+
+
+def test_sharded_image_path_on_one_rank_equals_the_unfused_bytes():
+    """sharding.run_sharded_images (preprocess output = send buffer, tensor2im before the gather) on ONE rank: the same
+    bytes as calling the two kernels around the step by hand; ragged source sizes"""
+    from instantrestore_amd import ops, sharding
+    from instantrestore_amd.preprocess import LanczosPreprocessor
+    g = torch.Generator().manual_seed(2)
+    total, n_refs, S = 3, 2, 64
+    images = [[torch.randint(0, 256, (70 + 9 * i + j, 90 + 5 * j, 3), generator=g, dtype=torch.uint8).cuda() for j in range(1 + n_refs)]
+              for i in range(total)]
+    step = lambda d, r: (d.float() * 0.6 + r.float().mean(dim=1) * 0.4).to(torch.float16)
+    got = sharding.run_sharded_images(step, images, total, n_refs, S, torch.float16, torch.device("cuda"))
+    packed = LanczosPreprocessor(S, torch.float16)([im for ident in images for im in ident]).view(total, 1 + n_refs, 3, S, S)
+    want = ops.tensor2im_u8(step(packed[:, 0], packed[:, 1:]))
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (total, S, S, 3) and torch.equal(got, want)

@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from instantrestore_amd.sharding import gather_identities, run_sharded, scatter_identities, shard_range, shard_sizes
+from instantrestore_amd.sharding import (gather_identities, run_sharded, run_sharded_images, scatter_identities, shard_range,
+                                         shard_sizes)
 
 
 def test_shard_ranges_cover_everything():
@@ -79,3 +80,62 @@ def test_two_rank_scatter_step_gather(total):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+# ---- the uint8 image path: preprocess output = send buffers, tensor2im before the gather --------
+def _cpu_preprocess(flat):      # stand-in for the HIP Lanczos preprocessor (no CPU fallback): equal-sized images only
+    x = torch.stack([im.permute(2, 0, 1).float() / 255.0 for im in flat])
+    return ((x - 0.5) / 0.5).to(torch.float16)
+
+
+def _cpu_tensor2im(x):          # the reference's tensor2im arithmetic (vis_utils.py:14-23) in the tensor's dtype
+    v = ((x * 0.5 + 0.5).clamp(0, 1) * 255).to(torch.uint8)
+    return v.permute(0, 2, 3, 1).contiguous()
+
+
+def _image_worker(rank, world, port, total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_refs, S = 2, 8
+        g = torch.Generator().manual_seed(1)
+        images = [[torch.randint(0, 256, (S, S, 3), generator=g, dtype=torch.uint8) for _ in range(1 + n_refs)] for _ in range(total)]
+        sent = {"n": 0, "dtypes": set()}
+        real_batch = dist.batch_isend_irecv
+
+        def counting(ops):
+            sent["n"] += len(ops)
+            sent["dtypes"].update(op.tensor.dtype for op in ops)
+            return real_batch(ops)
+
+        dist.batch_isend_irecv = counting
+        step = lambda d, r: (d.float() * 0.5 + r.float().mean(dim=1) * 0.5).to(torch.float16)
+        out = run_sharded_images(step, images if rank == 0 else None, total, n_refs, S, torch.float16, torch.device("cpu"),
+                                 preprocess=_cpu_preprocess, to_image=_cpu_tensor2im)
+        dist.batch_isend_irecv = real_batch
+        ok = True
+        if rank == 0:
+            packed = _cpu_preprocess([im for ident in images for im in ident]).view(total, 1 + n_refs, 3, S, S)
+            want = _cpu_tensor2im(step(packed[:, 0], packed[:, 1:]))
+            ok = out is not None and out.dtype == torch.uint8 and tuple(out.shape) == (total, S, S, 3) and torch.equal(out, want)
+            ok = ok and sent["n"] == 2 * (world - 1)           # ONE send per peer out, ONE receive per peer back
+        else:
+            ok = out is None and sent["n"] == 2
+        ok = ok and sent["dtypes"] == {torch.float16, torch.uint8}   # normalised tensors out, uint8 pixels back
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_uint8_image_path():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_image_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results

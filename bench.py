@@ -18,8 +18,10 @@ Conv/ResNet/VAE stages of the UNets are stock MIOpen/hipBLASLt work outside the 
 
 Inputs are what the reference's caller hands the processors (inference/test.py:61-83): fp32 module weights, fp32
 token activations (LayerNorm output), ``torch.autocast`` to the 16-bit compute dtype - the cast to 16 bit is part of the
-step.  Next to the headline (eager, two HIP streams) the line carries, labelled, under ``config.extras``: the same step
-on one stream, the same step replayed from ONE hipGraph, the step with cached reference K/V, an
+step.  The timed steps REPLAY one hipGraph of the two-stream step (captured once during warm-up: same launches, same work,
+no CPU launch gaps; ``--graph 0`` times eager launches, and a failed capture falls back to them and says so).  Next to
+the headline the line carries, labelled, under ``config.extras``: the same step with eager launches on one and on two
+streams, a second graph capture compared bit for bit with eager, the step with cached reference K/V, an
 end-to-end leg on the attention-topology host with the stage names of pix2pix_turbo.py:288-336, and the batch
 scatter / gather of SURVEY 8e over the process group (RCCL when N > 1).  None of them is ``value``.
 
@@ -196,7 +198,7 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         "algorithmic_gflop_per_launch": round(flops / 1e9, 2),
         "algorithmic_mb_per_launch": round(attn_bytes(B, L, lkv, C) / 1e6, 2),
         # HBM bytes per launch from a separate rocprofv3 --pmc pass of this kernel at this shape
-        # (tools/pmc_attn.sh -> profiles/r2_pmc_shared_attn.txt, r1_... if absent); FETCH_SIZE doubled per the
+        # (tools/pmc_attn.sh -> profiles/r3_pmc_shared_attn.txt, the r2_ / r1_ files if absent); FETCH_SIZE doubled per the
         # gfx950 correction of MI355X_MICROARCH.md.  null if the profile is not for this shape.
         "traffic": _pmc_traffic_bytes() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
         "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)" % _pmc_profile_name(),
@@ -246,7 +248,7 @@ def kernel_class_breakdown(layers, B, N, steps):
 
 
 def _pmc_profile_name():
-    for name in ("r2_pmc_shared_attn.txt", "r1_pmc_shared_attn.txt"):
+    for name in ("r3_pmc_shared_attn.txt", "r2_pmc_shared_attn.txt", "r1_pmc_shared_attn.txt"):
         if os.path.exists(os.path.join(REPO, "profiles", name)):
             return "profiles/" + name
     return "no committed PMC profile"
@@ -337,17 +339,17 @@ class CapturedStep:
     """the whole two-stream step captured once in ONE hipGraph (fork / join through the processors' events); ``replay()``
     re-runs it, ``outs`` / ``keys`` / ``vals`` are the graph's static result tensors"""
 
-    def __init__(self, layers, B, N):
+    def __init__(self, layers, B, N, two_streams=True):
         self.graph = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         saved = dict(_REF_STREAM)
         with torch.cuda.stream(s):
             _REF_STREAM.clear()
-            hot_path_step(layers, B, N, False, True)     # side stream + per-stream workspaces exist before the capture
+            hot_path_step(layers, B, N, False, two_streams)     # side stream + per-stream workspaces exist before the capture
             torch.cuda.synchronize()
             with torch.cuda.graph(self.graph, stream=s):
-                self.outs, self.keys, self.vals = hot_path_step(layers, B, N, False, True, return_kv=True)
+                self.outs, self.keys, self.vals = hot_path_step(layers, B, N, False, two_streams, return_kv=True)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         _REF_STREAM.clear()
@@ -569,6 +571,10 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B (ir_set_attn_variant); 0 = default")
     ap.add_argument("--two-streams", type=int, default=1,
                     help="1: reference-UNet layers on their own HIP stream, shared layer i waits for capture layer i only")
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1 (default): the timed steps REPLAY one hipGraph of the step (both streams, fork / join through the "
+                         "processors' events), captured once during warm-up - same launches, same work, no CPU launch gaps; "
+                         "0: eager launches (the round-1/2 headline; reported under config.extras either way)")
     ap.add_argument("--act-dtype", default="fp32", choices=["fp32", "lowp"],
                     help="fp32 (default): fp32 weights and token activations under torch.autocast, as inference/test.py:61-83 "
                          "runs the model (the 16-bit cast is part of the step); lowp: everything pre-cast to the 16-bit dtype")
@@ -612,23 +618,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    cap, launch_mode, graph_error = None, "eager launches", None
     with torch.no_grad():
         for _ in range(args.warmup):
             outs = hot_path_step(layers, B, N, args.ref_early_exit, bool(args.two_streams))
+        if args.graph and not args.ref_early_exit:
+            # the step captured ONCE (untimed, part of the warm-up); every timed step is one replay of that graph
+            try:
+                cap = CapturedStep(layers, B, N, bool(args.two_streams))
+                for _ in range(max(2, args.warmup)):     # untimed: the replayed step warmed up like the eager one
+                    cap.replay()
+                launch_mode = "hipGraph replay (one capture during warm-up)"
+            except Exception as e:      # capture is an optimisation: the eager step is always there
+                cap, graph_error = None, "%s: %s" % (type(e).__name__, e)
         barrier()
         # HIP events on the launch stream around the dominant kernel's launches INSIDE the timed region
-        # (the shared attention of the largest layer class: 3 launches per step)
+        # (the shared attention of the largest layer class: 3 launches per step) - eager launches only: inside a graph
+        # replay there is no launch to bracket, the in-step figure then comes from an eager run after the timing
         from instantrestore_amd import ops as _ops_mod
         top_l = layers[-1]["L"]
         in_step = []
-        if rank == 0 and not args.no_roofline:
+        if rank == 0 and not args.no_roofline and cap is None:
             _ops_mod.EVENT_SINK = (lambda q, rk, ad: rk is not None and q.shape[1] == top_l, in_step)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            outs = hot_path_step(layers, B, N, args.ref_early_exit, bool(args.two_streams))
+        if cap is not None:
+            for _ in range(args.steps):
+                cap.replay()
+            outs = cap.outs
+        else:
+            for _ in range(args.steps):
+                outs = hot_path_step(layers, B, N, args.ref_early_exit, bool(args.two_streams))
         barrier()   # synchronize + barrier + synchronize: the K steps are bracketed on both sides
         elapsed = time.perf_counter() - t0
         _ops_mod.EVENT_SINK = None
+        if rank == 0 and not args.no_roofline and cap is not None and args.two_streams:
+            _ops_mod.EVENT_SINK = (lambda q, rk, ad: rk is not None and q.shape[1] == top_l, in_step)
+            for _ in range(args.steps):
+                hot_path_step(layers, B, N, False, True)
+            torch.cuda.synchronize()
+            _ops_mod.EVENT_SINK = None
         in_step_ms = [a.elapsed_time(b) for a, b in in_step]
     assert all(torch.isfinite(o).all() for o in outs)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -684,13 +712,16 @@ def main():
             with torch.no_grad():
                 sec1 = _time_steps(lambda: hot_path_step(layers, B, N, args.ref_early_exit, False), args.steps)
                 extras["one_stream"] = {"images_per_s": round(B / sec1, 2), "ms_per_step": round(sec1 * 1e3, 4),
-                                        "note": "same step, both UNets on one HIP stream (the reference's own schedule)"}
+                                        "note": "same step, eager launches, both UNets on one HIP stream (the reference's own schedule)"}
+                sec2 = _time_steps(lambda: hot_path_step(layers, B, N, args.ref_early_exit, True), args.steps)
+                extras["eager_two_streams"] = {"images_per_s": round(B / sec2, 2), "ms_per_step": round(sec2 * 1e3, 4),
+                                               "note": "same step, eager launches on two HIP streams (the headline of rounds 1-2)"}
                 try:
                     secg, same, gdetail = extra_graph(layers, B, N, args.steps)
                     extras["hip_graph"] = {"images_per_s": round(B / secg, 2), "ms_per_step": round(secg * 1e3, 4),
                                            "bit_identical_to_eager": bool(same), "compared": gdetail,
-                                           "note": "the same two-stream step captured once in ONE hipGraph and replayed: same "
-                                                   "launches, same work, no launch gaps"}
+                                           "note": "a SECOND capture of the two-stream step, replayed and compared tensor by tensor "
+                                                   "(9 outputs + 18 harvested K/V) with a fresh eager run"}
                 except Exception as e:   # capture is an extra: never lose the headline over it
                     extras["hip_graph"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 keys, vals, cst = [], [], []
@@ -734,7 +765,7 @@ def main():
             "metric": "restored images/sec @512px, 4 refs, single-step; 1/2/4/8 MI355X",
             "metric_note": "one step = one pass of the HOT PATH only (attention path of both UNets, SURVEY 8a a-1..a-4): "
                            "identities pushed through it per second, NOT end-to-end restoration throughput (conv/ResNet/VAE "
-                           "stages are out of scope and not in the step); eager launches, two HIP streams",
+                           "stages are out of scope and not in the step); %s, %s" % (launch_mode, "two HIP streams" if args.two_streams else "one HIP stream"),
             "value": round(total_ids / (elapsed / args.steps), 3),
             "unit": "images/s",
             "n_gpus": world,
@@ -752,7 +783,7 @@ def main():
                             "attention, to_out) over B identities; UNet conv/ResNet and VAE stages are out of scope "
                             "and not in the step" % args.config,
                 "identities_per_gpu": B, "global_batch": total_ids, "refs": N, "px": px,
-                "use_adain": use_adain, "train_input": train_input, "ref_early_exit": bool(args.ref_early_exit), "two_streams": bool(args.two_streams), "parallelism": "dp%d (independent identities)" % world,
+                "use_adain": use_adain, "train_input": train_input, "ref_early_exit": bool(args.ref_early_exit), "two_streams": bool(args.two_streams), "launch": launch_mode, "graph_capture_error": graph_error, "parallelism": "dp%d (independent identities)" % world,
                 "activations": "fp32 under torch.autocast (test.py:61-83)" if act_fp32 else "pre-cast to the 16-bit dtype",
                 "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
                 "scatter_gather_ms": None if not extras else extras.get("scatter_gather", {}).get("scatter_gather_ms"),

@@ -172,7 +172,7 @@ enum {   // tile shapes (rows x columns of Y per workgroup); values are the `ker
   IR_LIN_TILE_256x64 = 3,    // 4 waves
   IR_LIN_TILE_64x128 = 4,    // 2 waves
   IR_LIN_TILE_128x256 = 5,   // 4 waves, 64 x 128 per wave
-  IR_LIN_TILE_256x256 = 6,   // 8 waves, 64 x 128 per wave
+  IR_LIN_TILE_256x256 = 6,   // 8 waves, 64 x 128 per wave, wave groups one phase apart (matrix phase beside load phase on every SIMD)
   IR_LIN_TILE_COUNT = 7
 };
 hipError_t ir_launch_linear_tiled(const LinearKParams& p, int dtype, int cfg, hipStream_t s);

@@ -247,6 +247,288 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) linear_tiled_kernel(const Lin
   }
 }
 
+
+// ---- 256 x 256 tile, PING-PONG wave groups ------------------------------------------------------------------------
+// Same tile, same LDS images and operand streams as linear_tiled_kernel<T, 4, 2, 2, 4, ...>; what changes is WHEN a wave
+// does what.  There, all eight waves leave the step's barrier in the same phase: both waves of a SIMD read fragments
+// together (matrix pipe idle) and then issue MFMAs together (each waits for the other's) - matrix time and
+// load time add up (profiles/r3_gemm_ablation.txt: 1.58 us per step for 1.02 us of MFMAs).  Here a K-step is four
+// barrier-separated phases per wave,
+//     M0 (8 + 8 MFMAs of k-substeps 0, 1) | L1 (fragments of k-substeps 2, 3) | M1 (their MFMAs) | L0' (fragments of the
+//     NEXT step's k-substeps 0, 1 + its LDS-DMA issue)
+// and waves 4-7 run ONE PHASE behind waves 0-3 (one extra barrier at their start, one at the others' end): a workgroup's
+// waves land on the SIMDs cyclically, so every SIMD has one wave in a matrix phase (16 MFMAs back to back, the pipe to
+// itself) beside one in a load phase (12 ds_read_b128, 8 LDS-DMA pieces or the fp32 loads / rounding / ds_write).
+// LDS-DMA of step k+1 is issued in L0(k) - its stage was last read in L1(k-1) of both groups, two barriers earlier - and
+// waited for (vmcnt(0), own pieces) at the end of L1(k); the first read of that stage is L0(k+1) of group A, one barrier
+// after group B's wait.  Every load phase ends with lgkmcnt(0): its fragment reads have left LDS before the barrier
+// after which another wave's DMA may overwrite that stage.
+template <typename T, bool XF32>
+__global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKParams p) {
+  using Tr = ElemTraits<T>;
+  using v8 = typename Tr::v8;
+  using v4 = typename Tr::v4;
+  constexpr int NW = 8, NT = 512, WN = 2, MI = 2, NI = 4;
+  constexpr int BM = 256, BN = 256;
+  constexpr int XT = BM * 128, WT = BN * 128, STAGE = XT + WT;
+  constexpr int XP = BM / 8 / NW, WP = BN / 8 / NW;    // 4 + 4 one-KiB pieces per wave and K-step
+  constexpr int XU = BM * 8 / NT;                      // fp32 path: 4 eight-element units per thread and K-step
+  constexpr int OUT_OFF = 2 * STAGE;                   // wave-private output staging (4 KiB each) BEHIND the stages
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm_tiled_pp[];
+  unsigned char* const smem = dsm_tiled_pp;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wid >> 2;                            // 0: waves 0-3, 1: waves 4-7 (one phase behind)
+  const int wm = wid / WN, wn = wid - wm * WN;
+  const int hi = lane >> 5, lq = lane & 31;
+  const int KT = p.K >> 6;
+
+  // ---- PERSISTENT workgroups: one per CU, each walks its share of its XCD's contiguous tile range --------------------------
+  // (round 3: a workgroup per tile cost ~12 us of launch, cold first stage and epilogue per tile against 1.2 us per K-step -
+  //  a third of the time at K = 1280, half at K = 640; here the next tile's first stage is in flight during the epilogue)
+  const int MT = (p.M + BM - 1) / BM, NTl = (p.N + BN - 1) / BN;   // the last column tile may be ragged (N % 64 == 0)
+  const int ntiles = MT * NTl;
+  const int xcd = blockIdx.x & 7, xs = blockIdx.x >> 3;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int t_start = (xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;   // xcd_remap's ranges
+  const int t_count = q8 + (xcd < r8 ? 1 : 0);
+  const int wg_x = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);       // workgroups of this launch on this XCD
+
+  // tile-independent lane coordinates
+  unsigned wvo[WP], xvo[XF32 ? 1 : XP];
+  int xlds0 = 0;                                       // fp32 path: unit j sits 64 rows (8 KiB, same swizzle) below unit 0
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    const int row = 8 * (wid + j * NW) + (lane >> 3);
+    wvo[j] = (unsigned)(row * p.w_ld * 2 + ((((lane & 7) ^ ((row >> 1) & 7))) << 4));
+  }
+  if constexpr (!XF32) {
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int row = 8 * (wid + j * NW) + (lane >> 3);
+      xvo[j] = (unsigned)(row * p.x_ld * 2 + ((((lane & 7) ^ ((row >> 1) & 7))) << 4));
+    }
+  } else {
+    const int row = tid >> 3, ch = tid & 7;
+    xlds0 = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+  }
+  int fread[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) fread[ks] = lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4);
+  const int xrow0 = wm * (MI * 32) * 128, wrow0 = XT + wn * (NI * 32) * 128;
+
+  // ---- per-tile operand streams -------------------------------------------------------------------------------------------
+  int m0 = 0, n0 = 0;
+  i32x4 wrs = {0, 0, 0, 0}, xrs = {0, 0, 0, 0};
+  const float* xtile = nullptr;                        // fp32 path: first row of the tile (wave-uniform) ...
+  unsigned xoff[XF32 ? XU : 1];                        // ... and the thread's byte offsets from it (32 bit: a tile spans < 4 GiB)
+  auto set_tile = [&](int logical) {
+    constexpr int GM = 8;
+    const int tgrp = logical / (GM * NTl), rem = logical - tgrp * (GM * NTl);
+    const int gm = (MT - tgrp * GM) < GM ? (MT - tgrp * GM) : GM;
+    const int tm = tgrp * GM + rem % gm, tn = rem / gm;
+    m0 = tm * BM; n0 = tn * BN;
+    const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
+    const int cols_valid = (p.N - n0) < BN ? (p.N - n0) : BN;
+    wrs = make_rsrc_words((const T*)p.w + (int64_t)n0 * p.w_ld, (unsigned)(((int64_t)(cols_valid - 1) * p.w_ld + p.K) * 2));   // rows past N read as zeros
+    if constexpr (!XF32) {
+      xrs = make_rsrc_words((const T*)p.x + (int64_t)m0 * p.x_ld, (unsigned)(((int64_t)(rows_valid - 1) * p.x_ld + p.K) * 2));
+    } else {
+      xtile = (const float*)p.x + (int64_t)m0 * p.x_ld;
+#pragma unroll
+      for (int j = 0; j < XU; ++j) {
+        const int row = (tid >> 3) + 64 * j;
+        const int rr = row < rows_valid ? row : rows_valid - 1;             // rows past M: copies of the last row (never stored)
+        xoff[j] = (unsigned)(rr * (int)p.x_ld + (tid & 7) * 8) * 4u;
+      }
+    }
+  };
+  f32x4 xr[XF32 ? XU : 1][2];
+  auto issue_w = [&](int kt, int slot) {
+    unsigned char* const sx = smem + slot * STAGE;
+#pragma unroll
+    for (int j = 0; j < WP; ++j) buffer_load_lds16_async(wrs, sx + XT + (wid + j * NW) * 1024, wvo[j] + kt * 128);
+  };
+  auto issue_x = [&](int kt, int slot) {
+    if constexpr (!XF32) {
+      unsigned char* const sx = smem + slot * STAGE;
+#pragma unroll
+      for (int j = 0; j < XP; ++j) buffer_load_lds16_async(xrs, sx + (wid + j * NW) * 1024, xvo[j] + kt * 128);
+    } else {
+#pragma unroll
+      for (int j = 0; j < XU; ++j) {
+        const unsigned o = xoff[j] + (unsigned)kt * 256u;
+        asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(xr[j][0]) : "v"(o), "s"(xtile) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:16" : "=v"(xr[j][1]) : "v"(o), "s"(xtile) : "memory");
+      }
+    }
+  };
+  auto land_stage = [&](int slot) {                     // own transfers have landed; fp32: rounded and written to LDS
+    if constexpr (XF32) {
+      unsigned char* const sx = smem + slot * STAGE;
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xr[0][0]), "+v"(xr[0][1]) : : "memory");
+#pragma unroll
+      for (int j = 1; j < XU; ++j) asm volatile("" : "+v"(xr[j][0]), "+v"(xr[j][1]));
+#pragma unroll
+      for (int j = 0; j < XU; ++j) {
+        const f32x8 f = __builtin_shufflevector(xr[j][0], xr[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+        *(IR_LDS v8*)(IR_LDS unsigned char*)(sx + xlds0 + j * 8192) = __builtin_convertvector(f, v8);
+      }
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+
+  f32x16 acc[MI][NI];
+  v8 wf[2][NI], xf[2][MI];                              // fragments of TWO k-substeps: what one matrix phase consumes
+  auto load_frags = [&](int slot, int half) {           // k-substeps 2*half, 2*half + 1 of the stage in `slot`
+    const unsigned char* const st = smem + slot * STAGE;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[q][ni] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(st + wrow0 + ni * 4096 + fread[2 * half + q]);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) xf[q][mi] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(st + xrow0 + mi * 4096 + fread[2 * half + q]);
+    }
+  };
+  auto matrix_phase = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Tr::mfma(wf[q][ni], xf[q][mi], acc[mi][ni]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto phase_end = [&]() {   // fragment reads and LDS writes of this phase have left LDS; then the workgroup-wide rendezvous
+    __builtin_amdgcn_sched_barrier(0);      // nothing (MFMAs are register-only: hipcc would float them) crosses a phase boundary
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // epilogue of the tile at (em0, en0): column scale, bias, ONE rounding, transposed through the wave's PRIVATE 4-KiB
+  // staging area (16 rows x 144 B at a time) into whole 128-byte lines of Y.  No barrier, and nothing of it touches the
+  // operand stages: the next tile's first stage lands in them meanwhile.
+  auto epilogue = [&](int em0, int en0) {
+    unsigned char* const tb = smem + OUT_OFF + wid * 4096;
+#pragma unroll
+    for (int nh = 0; nh < NI / 2; ++nh) {
+      const int ncol0 = en0 + wn * (NI * 32) + nh * 64;
+      if (ncol0 >= p.N) break;                            // whole 64-column group past N (wave-uniform)
+      v4 bvs[2][4];
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bvs[n2][g] = *(const v4*)((const T*)p.bias + ncol0 + n2 * 32 + 8 * g + 4 * hi);
+      } else {
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bvs[n2][g] = v4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          if ((lq >> 4) == half) {
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+              const float cs = (ncol0 + n2 * 32) < p.scale_cols ? p.col_scale : 1.0f;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                f32x4 f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) f[i] = acc[mi][2 * nh + n2][4 * g + i] * cs + (float)bvs[n2][g][i];
+                *(v4*)(tb + (lq & 15) * kTiledPitch + n2 * 64 + (8 * g + 4 * hi) * 2) = __builtin_convertvector(f, v4);
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int r = 8 * j + (lane >> 3);
+            const u32x4 v = *(const u32x4*)(tb + r * kTiledPitch + (lane & 7) * 16);
+            const int row = em0 + wm * (MI * 32) + mi * 32 + half * 16 + r;
+            if (row < p.M) *(u32x4*)((T*)p.y + (int64_t)row * p.y_ld + ncol0 + (lane & 7) * 8) = v;
+          }
+        }
+      }
+    }
+  };
+
+  // ---- walk the tiles ---------------------------------------------------------------------------------------------------------
+  if (xs >= t_count) return;                             // more workgroups than tiles on this XCD (tiny problems)
+  set_tile(t_start + xs);
+  issue_w(0, 0);
+  issue_x(0, 0);
+  for (int tl = xs; tl < t_count; tl += wg_x) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    // stage 0 of this tile is in flight (issued above / before the previous tile's epilogue)
+    land_stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    phase_end();
+    load_frags(0, 0);                                      // L0(0)
+    if (KT > 1) { issue_w(1, 1); issue_x(1, 1); }
+    if (grp == 1) phase_end();                             // waves 4-7 run one phase behind
+    for (int kt = 0; kt < KT; ++kt) {
+      const int cur = kt & 1;
+      matrix_phase();                                      // M0(kt)
+      phase_end();
+      load_frags(cur, 1);                                  // L1(kt); the wave's transfers of step kt+1 (issued in L0(kt)) land
+      if (kt + 1 < KT) land_stage(cur ^ 1);
+      phase_end();
+      matrix_phase();                                      // M1(kt)
+      phase_end();
+      if (kt + 1 < KT) {                                   // L0(kt+1) + issue of step kt+2 into the stage last read two barriers back
+        load_frags(cur ^ 1, 0);
+        if (kt + 2 < KT) { issue_w(kt + 2, cur); issue_x(kt + 2, cur); }
+      }
+      phase_end();
+    }
+    if (grp == 0) phase_end();
+    // every wave is behind everybody's last fragment read: the stages are free.  Next tile's first stage goes out NOW.
+    const int em0 = m0, en0 = n0;
+    const bool more = tl + wg_x < t_count;
+    if (more) {
+      set_tile(t_start + tl + wg_x);
+      issue_w(0, 0);
+      if constexpr (!XF32) issue_x(0, 0);                  // (fp32: its staging registers would be live across the epilogue)
+    }
+    epilogue(em0, en0);
+    if constexpr (XF32) { if (more) issue_x(0, 0); }
+  }
+}
+
+template <typename T, bool XF32>
+hipError_t launch_pp(const LinearKParams& p, hipStream_t s) {
+  constexpr size_t dyn = 2 * (size_t)(256 + 256) * 128 + 8 * 4096;   // two operand stages + the waves' output staging: all of LDS
+  static bool attr_set[64] = {};
+  static int n_cu[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
+  if (!attr_set[dev]) {
+    hipError_t ea = hipFuncSetAttribute((const void*)linear_tiled_pp_kernel<T, XF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    if (ea != hipSuccess) return ea;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    n_cu[dev] = cus;
+    attr_set[dev] = true;
+  }
+  const int MT = (p.M + 255) / 256, NTl = (p.N + 255) / 256;
+  const int ntiles = MT * NTl;
+  const int grid = ntiles < n_cu[dev] ? ntiles : n_cu[dev];   // persistent: one workgroup per CU (all of its LDS)
+  hipLaunchKernelGGL((linear_tiled_pp_kernel<T, XF32>), dim3((unsigned)grid), dim3(512), dyn, s, p);
+  return hipGetLastError();
+}
+
 template <typename T, int WM, int WN, int MI, int NI, bool XF32, bool ILV>
 hipError_t launch_cfg(const LinearKParams& p, hipStream_t s) {
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
@@ -277,7 +559,8 @@ hipError_t launch_x(const LinearKParams& p, int cfg, hipStream_t s) {
     case IR_LIN_TILE_256x64: return launch_cfg<T, 4, 1, 2, 2, XF32, I>(p, s);
     case IR_LIN_TILE_64x128: return launch_cfg<T, 1, 2, 2, 2, XF32, I>(p, s);
     case IR_LIN_TILE_128x256: return launch_cfg<T, 2, 2, 2, 4, XF32, I>(p, s);
-    case IR_LIN_TILE_256x256: return launch_cfg<T, 4, 2, 2, 4, XF32, I>(p, s);
+    case IR_LIN_TILE_256x256: return launch_pp<T, XF32>(p, s);   // wave groups one phase apart: 1-4 % over the same tile with all
+                                                                  // waves in one phase (launch_cfg<T, 4, 2, 2, 4, XF32, I>), and a ragged last column tile
     default: return hipErrorInvalidValue;
   }
 }
@@ -299,7 +582,8 @@ bool ir_linear_tiled_cfg_ok(int cfg, int N) {
   switch (cfg) {
     case IR_LIN_TILE_256x128: case IR_LIN_TILE_128x128: case IR_LIN_TILE_64x128: return N % 128 == 0;
     case IR_LIN_TILE_128x64: case IR_LIN_TILE_256x64: return N % 64 == 0;
-    case IR_LIN_TILE_128x256: case IR_LIN_TILE_256x256: return N % 256 == 0;
+    case IR_LIN_TILE_128x256: return N % 256 == 0;
+    case IR_LIN_TILE_256x256: return N % 64 == 0;         // ragged last column tile
     default: return false;
   }
 }

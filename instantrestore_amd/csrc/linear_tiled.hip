@@ -17,6 +17,7 @@
 // it tiles are ordered 8 row panels x all column tiles, so the ~64 tiles resident on an XCD at a time form an 8 x 8
 // patch that shares its X and W panels in that L2.
 // Deterministic: no atomics, no split-K; the accumulation order of an output element is fixed by the tile shape.
+#include <stdlib.h>
 #include <type_traits>
 
 #include "ir_common.h"
@@ -285,9 +286,10 @@ __global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKPa
   const int hi = lane >> 5, lq = lane & 31;
   const int KT = p.K >> 6;
 
-  // ---- PERSISTENT workgroups: one per CU, each walks its share of its XCD's contiguous tile range --------------------------
-  // (round 3: a workgroup per tile cost ~12 us of launch, cold first stage and epilogue per tile against 1.2 us per K-step -
-  //  a third of the time at K = 1280, half at K = 640; here the next tile's first stage is in flight during the epilogue)
+  // ---- tile walk: a workgroup takes tiles xs, xs + (workgroups on its XCD), ... of its XCD's contiguous range - exactly one
+  // when the launch has a workgroup per tile (the default), several when it is persistent (one workgroup per CU; then the
+  // next tile's first stage is in flight during the epilogue).  Measured equal: the ~6.5 us per tile beyond the K loop are
+  // the output write (HBM-bound burst), not launch or a cold first stage (profiles/r3_gemm_ablation.txt)
   const int MT = (p.M + BM - 1) / BM, NTl = (p.N + BN - 1) / BN;   // the last column tile may be ragged (N % 64 == 0)
   const int ntiles = MT * NTl;
   const int xcd = blockIdx.x & 7, xs = blockIdx.x >> 3;
@@ -524,7 +526,12 @@ hipError_t launch_pp(const LinearKParams& p, hipStream_t s) {
   }
   const int MT = (p.M + 255) / 256, NTl = (p.N + 255) / 256;
   const int ntiles = MT * NTl;
-  const int grid = ntiles < n_cu[dev] ? ntiles : n_cu[dev];   // persistent: one workgroup per CU (all of its LDS)
+  // One workgroup per tile by default: the hardware dispatcher then balances the tiles against whatever the other stream
+  // runs on the chip.  IR_LIN_PERSISTENT=1 (development A/B) launches one workgroup per CU that walks its share of the
+  // tiles with the next tile's first stage in flight during the epilogue - measured equal in isolation and in the step
+  // (profiles/r3_gemm_ablation.txt), and a late-starting persistent workgroup would hold its statically assigned tiles back.
+  static const bool persistent = getenv("IR_LIN_PERSISTENT") != nullptr;
+  const int grid = (persistent && ntiles > n_cu[dev]) ? n_cu[dev] : ntiles;
   hipLaunchKernelGGL((linear_tiled_pp_kernel<T, XF32>), dim3((unsigned)grid), dim3(512), dyn, s, p);
   return hipGetLastError();
 }

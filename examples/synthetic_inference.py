@@ -54,7 +54,8 @@ def main(argv=None):
     import __graft_entry__ as ge
     from face_replace.models.attn_processors import register_attention_processor, register_attention_processor_kv_unet
     from instantrestore_amd import ops
-    from instantrestore_amd.kv_harvest import enable_stream_overlap, harvest_reference_kv
+    from instantrestore_amd.kv_cache import ReferenceKVCache
+    from instantrestore_amd.kv_harvest import enable_ref_stats, enable_stream_overlap, harvest_reference_kv
     from instantrestore_amd.attn_processors import ReferenceCaptureComplete, AttnProcessor
     from instantrestore_amd.preprocess import LanczosPreprocessor
     from instantrestore_amd.unet_host import AttnTopologyUNet
@@ -70,6 +71,7 @@ def main(argv=None):
     register_attention_processor_kv_unet(original_unet)
     register_attention_processor(unet, cfg)
     enable_stream_overlap(original_unet)
+    enable_ref_stats(original_unet)        # the capture layers also stash the AdaIN content statistics of every reference V
     vae = StandInVAE().to(dev)
     caption = torch.randn(1, 77, cross, device=dev)          # fixed caption embedding (pix2pix_turbo.py:100-106)
 
@@ -100,12 +102,22 @@ def main(argv=None):
                 pass
         for p in procs:
             p.stop_after_capture = None
-        keys, values, events = harvest_reference_kv(original_unet, N, [N] * B, with_events=True)
+        keys, values, events, stats = harvest_reference_kv(original_unet, N, [N] * B, with_events=True, with_stats=True)
         # main branch: every shared layer waits for its own reference layer only
         z = unet(vae.encode(x), None, encoder_hidden_states=caption.expand(B, -1, -1),
-                 cross_attention_kwargs={"ref_keys": keys, "ref_values": values, "ref_events": events}).sample
+                 cross_attention_kwargs={"ref_keys": keys, "ref_values": values, "ref_events": events, "ref_stats": stats}).sample
         torch.cuda.current_stream().wait_stream(side)
         out_u8 = ops.tensor2im_u8(vae.decode(z))              # (B, S, S, 3) uint8
+        # NEXT FRAME of the same identities: the references have not changed, so neither have their K/V nor their AdaIN
+        # content statistics - both come out of the per-identity cache and the whole reference branch is skipped
+        cache = ReferenceKVCache(max_identities=max(8, B))
+        for b in range(B):
+            cache.get_or_compute("id%d" % b, lambda b=b: ([k[b:b + 1] for k in keys], [v[b:b + 1] for v in values],
+                                                          [(m[b:b + 1], sd[b:b + 1]) for m, sd in stats]))
+        ck, cv, cs = cache.assemble(["id%d" % b for b in range(B)])
+        z2 = unet(vae.encode(x), None, encoder_hidden_states=caption.expand(B, -1, -1),
+                  cross_attention_kwargs={"ref_keys": ck, "ref_values": cv, "ref_stats": cs}).sample
+        assert torch.equal(ops.tensor2im_u8(vae.decode(z2)), out_u8), "cached K/V + statistics must reproduce the frame"
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert out_u8.shape == (B, S, S, 3) and out_u8.dtype == torch.uint8

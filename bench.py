@@ -228,18 +228,20 @@ def kernel_class_breakdown(layers, B, N, steps):
             return r
         return w
 
-    saved = (ops.shared_attention, ops.linear, ops.adain_stats)
+    saved = (ops.shared_attention, ops.linear, ops.adain_stats, ops.adain_stats_cached, ops.token_stats)
     ops.shared_attention = timed(saved[0], lambda q, k, v, rk=None, rv=None, **kw:
                                  "attention L=%d %s" % (q.shape[1], "shared" if rk is not None else "capture"))
     ops.linear = timed(saved[1], lambda x, w, b=None, **kw: "projection GEMM K=%d" % w.shape[1])
     ops.adain_stats = timed(saved[2], lambda v, rv, **kw: "AdaIN statistics")
+    ops.adain_stats_cached = timed(saved[3], lambda v, m, sd, **kw: "AdaIN statistics")
+    ops.token_stats = timed(saved[4], lambda x, **kw: "AdaIN statistics")
     try:
         with torch.no_grad():
             for _ in range(steps):
                 hot_path_step(layers, B, N, False, False)
         torch.cuda.synchronize()
     finally:
-        ops.shared_attention, ops.linear, ops.adain_stats = saved
+        ops.shared_attention, ops.linear, ops.adain_stats, ops.adain_stats_cached, ops.token_stats = saved
     tot = {}
     for label, e0, e1 in rec:
         tot[label] = tot.get(label, 0.0) + e0.elapsed_time(e1)

@@ -298,7 +298,7 @@ int ir_freeu_fourier_filter(int32_t dtype, int64_t planes, int32_t height, int32
  * (no atomics, no split-K reduction through memory):
  *   - X-stationary (K in {64, 128, ..., 320}, and K = 640 with the contraction split over two waves whose fp32
  *     partial tiles meet in LDS): X is read once and kept in registers, W streams through LDS; N % 32 == 0,
- *     N <= 4096 with bias.  Chosen for large M (M * N >= 2^24; 2^25 at K = 640).
+ *     N <= 4096 with bias.  Chosen for large M (M >= 65536 rows).
  *   - LDS-tiled (any K % 64 == 0, N % 64 == 0): 256x256 ... 64x128 tiles of Y, both operands through swizzled LDS
  *     stages; K = 1280 and the small-M shapes of every class.
  * Other shapes return IR_ERR_UNSUPPORTED.

@@ -408,9 +408,9 @@ int ir_linear_kernel_for(int64_t m, int32_t n, int32_t k, int32_t has_bias) {
   if (!xs && !tiled) return -1;
   if (!tiled) return IR_LIN_X_STATIONARY;
   // the X-stationary kernels read X once (and cast fp32 activations once) and win where that is the traffic that
-  // matters: large M.  Thresholds from profiles/r3_gemm_probe.txt: K <= 320 from 2^24 output elements (32768 x 960 yes,
-  // 32768 x 320 no), K = 640 from 2^25 (32768 x 1920 yes, 32768 x 640 no)
-  if (xs && m * (int64_t)n >= (k == 640 ? (1LL << 25) : (1LL << 24))) return IR_LIN_X_STATIONARY;
+  // matters: large M.  From profiles/r3_gemm_probe_final.txt: at 131072 rows they lead (K = 320: 122 vs 167 us), at 32768
+  // rows the 256x256 tile leads or ties (32768 x 960 x 320: 33 vs 43 us; x 1920 x 640: 100 vs 100; x 640 x 640: 39-46 vs 44-54)
+  if (xs && m >= 65536) return IR_LIN_X_STATIONARY;
   return IR_LIN_TILED_FIRST + ir_linear_tiled_pick(m, n);
 }
 

@@ -574,13 +574,13 @@ hipError_t launch_x(const LinearKParams& p, int cfg, hipStream_t s) {
 
 }  // namespace
 
-// tile shape for a problem, from the measurements of tools/gpu_gemm_probe3.py (profiles/r3_gemm_probe.txt): the 256x256
-// tile (64 x 128 per wave: 0.75 LDS fragment reads per MFMA, half the L2 traffic per flop of 128x128) wins as soon as
-// its grid covers ~160 of the 256 CUs; below that 128x128 at two workgroups per CU, and 64-row tiles when even that
-// grid leaves CUs idle
+// tile shape for a problem, from the measurements of tools/gpu_gemm_probe3.py (profiles/r3_gemm_probe*.txt): the 256x256
+// tile (64 x 128 per wave: 0.75 LDS fragment reads per MFMA, half the L2 traffic per flop of 128x128; ragged last column
+// tile allowed) wins as soon as its grid covers ~160 of the 256 CUs; below that 128x128 at two workgroups per CU, and
+// 64-row tiles when even that grid leaves CUs idle
 int ir_linear_tiled_pick(int64_t M, int N) {
-  auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (int64_t)(N / bn); };
-  if (N % 256 == 0 && tiles(256, 256) >= 160) return IR_LIN_TILE_256x256;
+  auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (int64_t)((N + bn - 1) / bn); };
+  if (tiles(256, 256) >= 160) return IR_LIN_TILE_256x256;
   if (N % 128 == 0) return tiles(128, 128) >= 128 ? IR_LIN_TILE_128x128 : IR_LIN_TILE_64x128;
   return tiles(256, 64) >= 512 ? IR_LIN_TILE_256x64 : IR_LIN_TILE_128x64;
 }

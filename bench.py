@@ -459,10 +459,11 @@ def extra_e2e(B, N, px, dtype, steps, dev):
         ev[1].record()
         zx, zc = vae.encode(x), vae.encode(cond)
         ev[2].record()
-        keys, vals = get_conditioning_keys_values(original_unet, zc, None, caption.expand(B * N, -1, -1), N, [N] * B)
+        keys, vals, stats = get_conditioning_keys_values(original_unet, zc, None, caption.expand(B * N, -1, -1), N, [N] * B,
+                                                         with_stats=True)   # one stream: AdaIN content statistics from the capture layers
         ev[3].record()
         z = unet(zx, None, encoder_hidden_states=caption.expand(B, -1, -1),
-                 cross_attention_kwargs={"ref_keys": keys, "ref_values": vals}).sample
+                 cross_attention_kwargs={"ref_keys": keys, "ref_values": vals, "ref_stats": stats}).sample
         ev[4].record()
         out = ops.tensor2im_u8(vae.decode(z))
         ev[5].record()

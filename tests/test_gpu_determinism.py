@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("cfg,train_input", [("cfg2", True), ("cfg2", False)])
+@pytest.mark.parametrize("cfg,train_input", [("cfg2", True), ("cfg2", False), ("cfg4", True)])
 def test_bench_step_is_bit_identical_on_one_stream_two_streams_and_graph_replay(cfg, train_input):
     import bench
     dev = torch.device("cuda", 0)

@@ -163,6 +163,9 @@ struct LinearKParams {
   float col_scale;      // (scale_cols % 32 == 0; 0 = none): the softmax scale * log2(e) on the q third of a fused q/k/v
 };
 hipError_t ir_launch_linear_skinny(const LinearKParams& p, int dtype, hipStream_t s);
+// linear_xs_pp.hip: the X-stationary kernel at K = 320 with ping-pong wave groups (8 waves, one workgroup per CU)
+hipError_t ir_launch_linear_xs_pp(const LinearKParams& p, int dtype, hipStream_t s);
+bool ir_linear_xs_pp_covers(int N, int K, bool has_bias);
 
 // ---- linear_tiled.hip: LDS-tiled Y = X W^T (+ bias) for any K % 64 == 0, N % 64 == 0 (K = 1280, small-M shapes) ----
 enum {   // tile shapes (rows x columns of Y per workgroup); values are the `kernel` argument of ir_linear_fwd_ex minus 2

@@ -337,6 +337,57 @@ def _time_steps(fn, steps, warm=3):
     return (time.perf_counter() - t0) / steps
 
 
+def power_probe(step_fn, seconds=3.0):
+    """board power and shader clock while the step runs back to back for `seconds` (rocm-smi from a side thread): the step
+    is power-capped on random data, and the clock the kernels get is what the cap leaves - the roofline peaks are quoted at
+    the 2.4 GHz the chip only holds on idle-ish or all-zero workloads"""
+    import shutil
+    import subprocess
+    import threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(smi):
+        return {"error": "rocm-smi not found"}
+    samples, stop = [], []
+
+    def sampler():
+        while not stop:
+            try:
+                out = subprocess.run([smi, "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=10).stdout
+                rows = [r for r in out.strip().splitlines() if r.strip()]
+                head, vals = rows[0].split(","), rows[1].split(",")
+                rec = dict(zip(head, vals))
+                w = [float(v) for k, v in rec.items() if "Power" in k and v.replace(".", "", 1).isdigit()]
+                c = [float(v.strip("()").lower().replace("mhz", "")) for k, v in rec.items() if k.startswith("sclk clock speed")]
+                if w and c:
+                    samples.append((w[0], c[0]))
+            except Exception:   # a sample lost is a sample lost
+                pass
+            time.sleep(0.2)
+
+    for _ in range(3):
+        step_fn()
+    torch.cuda.synchronize()
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            step_fn()
+        n += 10
+        torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / n
+    stop.append(1)
+    th.join(timeout=15)
+    body = samples[1:] if len(samples) > 2 else samples    # the first sample may predate the load
+    if not body:
+        return {"error": "no rocm-smi sample parsed", "ms_per_step_sustained": round(sec * 1e3, 4)}
+    return {"watts_avg": round(sum(w for w, _ in body) / len(body), 1), "watts_max": round(max(w for w, _ in body), 1),
+            "sclk_mhz_avg": round(sum(c for _, c in body) / len(body), 1), "samples": len(body),
+            "ms_per_step_sustained": round(sec * 1e3, 4), "steps": n, "board_cap_watts": 1400, "sclk_peak_mhz": 2400,
+            "note": "%.0f s of back-to-back steps with rocm-smi sampled beside them; roofline peaks assume 2.4 GHz" % seconds}
+
+
 class CapturedStep:
     """the whole two-stream step captured once in ONE hipGraph (fork / join through the processors' events); ``replay()``
     re-runs it, ``outs`` / ``keys`` / ``vals`` are the graph's static result tensors"""
@@ -742,6 +793,11 @@ def main():
                                        "note": "reference K/V served from the per-identity cache (SURVEY 8f rank 2): only the nine "
                                                "shared layers run; valid when the references of an identity repeat across frames"}
                 del keys, vals, cst
+                try:
+                    pstep = cap.replay if cap is not None else (lambda: hot_path_step(layers, B, N, args.ref_early_exit, bool(args.two_streams)))
+                    extras["power"] = power_probe(pstep, float(os.environ.get("IR_BENCH_POWER_SECONDS", "3")))
+                except Exception as e:
+                    extras["power"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 if args.config != "cfg5":
                     try:
                         extras["e2e_topology_host"] = extra_e2e(B, N, px, dtype, max(2, args.steps // 2), dev)

@@ -320,7 +320,6 @@ int ir_linear_fwd_scaled(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, 
 #define IR_LIN_X_STATIONARY 1
 #define IR_LIN_TILED_FIRST 2    /* 2: 256x128, 3: 128x128, 4: 128x64, 5: 256x64, 6: 64x128, 7: 128x256, 8: 256x256 (rows x columns of Y per
                                    workgroup; the last two with 64 x 128 per wave) */
-#define IR_LIN_X_STATIONARY_PP 9 /* X-stationary, K = 320 only: 8-wave workgroups whose two wave groups run one phase apart */
 int ir_linear_fwd_ex(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                      int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
                      int32_t kernel, void* stream);

@@ -426,13 +426,18 @@ int ir_linear_fwd_ex(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int3
   if (kernel == IR_LIN_X_STATIONARY) {
     if (!x_stationary_covers(n, k, bias))
       return fail(IR_ERR_UNSUPPORTED, "X-stationary kernel: K in {64,...,320} or 640, N %% 32 == 0, N <= %d with bias (K = %d, N = %d)", kLinearMaxBiasN, k, n);
+#ifdef IR_ABLATIONS   // tools/experiments/linear_xs_{pp,rot}.hip: development builds only
   } else if (kernel == IR_LIN_X_STATIONARY_PP) {
     if ((int64_t)m * y_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "X-stationary ping-pong kernel: Y spans 2 GiB or more");
     if (!ir_linear_xs_pp_covers(n, k, bias != nullptr))
       return fail(IR_ERR_UNSUPPORTED, "X-stationary ping-pong kernel: K = 320, N %% 32 == 0, N <= %d with bias (K = %d, N = %d)", kLinearMaxBiasN, k, n);
+  } else if (kernel == IR_LIN_X_STATIONARY_ROT) {
+    if ((int64_t)m * y_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "X-stationary rotated kernel: Y spans 2 GiB or more");
+    if (!ir_linear_xs_rot_covers(n, k, bias != nullptr))
+      return fail(IR_ERR_UNSUPPORTED, "X-stationary rotated kernel: K = 320, N %% 32 == 0, N <= %d with bias (K = %d, N = %d)", kLinearMaxBiasN, k, n);
+#endif
   } else if (kernel < IR_LIN_TILED_FIRST || kernel >= IR_LIN_TILED_FIRST + IR_LIN_TILE_COUNT) {
-    return fail(IR_ERR_INVALID_ARG, "kernel %d: 0 auto, 1 X-stationary, %d..%d tiled, %d X-stationary ping-pong", kernel, IR_LIN_TILED_FIRST,
-                IR_LIN_TILED_FIRST + IR_LIN_TILE_COUNT - 1, IR_LIN_X_STATIONARY_PP);
+    return fail(IR_ERR_INVALID_ARG, "kernel %d: 0 auto, 1 X-stationary, %d..%d tiled", kernel, IR_LIN_TILED_FIRST, IR_LIN_TILED_FIRST + IR_LIN_TILE_COUNT - 1);
   } else if (k % 64 != 0 || !ir_linear_tiled_cfg_ok(kernel - IR_LIN_TILED_FIRST, n)) {
     return fail(IR_ERR_UNSUPPORTED, "tiled kernel %d: K %% 64 == 0 and N a multiple of the tile width (K = %d, N = %d)", kernel, k, n);
   }
@@ -447,9 +452,13 @@ int ir_linear_fwd_ex(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int3
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.x_ld = x_ld; p.w_ld = w_ld; p.y_ld = y_ld;
   p.M = (int32_t)m; p.N = n; p.K = k; p.nsplit = 1;
   p.scale_cols = scale_cols; p.col_scale = col_scale; p.x_f32 = x_is_f32 ? 1 : 0;
-  const hipError_t e = kernel == IR_LIN_X_STATIONARY      ? ir_launch_linear_skinny(p, dtype, (hipStream_t)stream)
-                       : kernel == IR_LIN_X_STATIONARY_PP ? ir_launch_linear_xs_pp(p, dtype, (hipStream_t)stream)
-                                                          : ir_launch_linear_tiled(p, dtype, kernel - IR_LIN_TILED_FIRST, (hipStream_t)stream);
+  const hipError_t e =
+#ifdef IR_ABLATIONS
+      kernel == IR_LIN_X_STATIONARY_PP    ? ir_launch_linear_xs_pp(p, dtype, (hipStream_t)stream)
+      : kernel == IR_LIN_X_STATIONARY_ROT ? ir_launch_linear_xs_rot(p, dtype, (hipStream_t)stream) :
+#endif
+      kernel == IR_LIN_X_STATIONARY ? ir_launch_linear_skinny(p, dtype, (hipStream_t)stream)
+                                    : ir_launch_linear_tiled(p, dtype, kernel - IR_LIN_TILED_FIRST, (hipStream_t)stream);
   if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "linear launch: %s", hipGetErrorString(e));
   return IR_OK;
 }

@@ -163,9 +163,13 @@ struct LinearKParams {
   float col_scale;      // (scale_cols % 32 == 0; 0 = none): the softmax scale * log2(e) on the q third of a fused q/k/v
 };
 hipError_t ir_launch_linear_skinny(const LinearKParams& p, int dtype, hipStream_t s);
-// linear_xs_pp.hip: the X-stationary kernel at K = 320 with ping-pong wave groups (8 waves, one workgroup per CU)
-hipError_t ir_launch_linear_xs_pp(const LinearKParams& p, int dtype, hipStream_t s);
+#ifdef IR_ABLATIONS   // development builds (tools/experiments/build.sh): two other schedules of the K = 320 case, kernel ids 9 and 10
+constexpr int IR_LIN_X_STATIONARY_PP = 9, IR_LIN_X_STATIONARY_ROT = 10;
+hipError_t ir_launch_linear_xs_pp(const LinearKParams& p, int dtype, hipStream_t s);    // ping-pong wave groups
 bool ir_linear_xs_pp_covers(int N, int K, bool has_bias);
+hipError_t ir_launch_linear_xs_rot(const LinearKParams& p, int dtype, hipStream_t s);   // row blocks rotated: staging / stores between the MFMAs
+bool ir_linear_xs_rot_covers(int N, int K, bool has_bias);
+#endif
 
 // ---- linear_tiled.hip: LDS-tiled Y = X W^T (+ bias) for any K % 64 == 0, N % 64 == 0 (K = 1280, small-M shapes) ----
 enum {   // tile shapes (rows x columns of Y per workgroup); values are the `kernel` argument of ir_linear_fwd_ex minus 2

@@ -119,52 +119,6 @@ def test_tiled_linear_exact_layout(kernel):
     assert torch.equal(y.float(), ref.to(torch.bfloat16).float())
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
-@pytest.mark.parametrize("M,N,bias", [
-    (131072, 960, False), (131072, 320, True), (65536, 640, False), (512, 64, True), (1, 32, False), (513, 96, True),
-    (70001, 352, True), (4099, 2880, False), (40000, 32, True),
-])
-def test_x_stationary_ping_pong_is_the_x_stationary_kernel_bit_for_bit(dtype, M, N, bias):
-    """linear_xs_pp.hip (K = 320): the same products accumulated in the same order as linear_skinny.hip - only the schedule
-    differs - so the two kernels must agree in every bit; fp32 activations, the column scale, ragged M, odd chunk counts
-    (N = 96, 352: a half-line tail per range) and single chunks included.  The float64 check of the same shapes is
-    test_linear_matches_float64's, which the old kernel passes."""
-    from instantrestore_amd import ops
-    K = 320
-    g = torch.Generator().manual_seed(M + N)
-    x32 = torch.randn(M, K, generator=g).cuda()
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).cuda()
-    b = torch.randn(N, generator=g).to(dtype).cuda() if bias else None
-    for x in (x32.to(dtype), x32):
-        for kw in ({}, {"scale_cols": 32, "col_scale": 0.125 * 1.4426950408889634}):
-            a = ops.linear(x, w, b, kernel=ops.LIN_KERNELS["x_stationary"], **kw)
-            c = ops.linear(x, w, b, kernel=ops.LIN_KERNELS["x_stationary_pp"], **kw)
-            assert torch.equal(a, c), (x.dtype, kw, (a != c).nonzero()[:4])
-    ref = x32.to(dtype).double() @ w.double().T + (b.double() if bias else 0.0)
-    y = ops.linear(x32, w, b, kernel=ops.LIN_KERNELS["x_stationary_pp"])
-    assert ((y.double() - ref).abs() <= TOL[dtype] * ref.abs().clamp_min(1.0)).all()
-
-
-def test_x_stationary_ping_pong_exact_layout_and_untouched_neighbours():
-    """integer operands (exact products), strided x rows, a row slice of a fused weight, Y a column slice of a wider
-    buffer: columns outside the slice and rows past M keep their bytes"""
-    from instantrestore_amd import ops, _lib
-    g = torch.Generator().manual_seed(5)
-    M, N, K = 1500, 160, 320
-    xbig = torch.randint(-3, 4, (M, K + 64), generator=g).to(torch.bfloat16).cuda()
-    x = xbig[:, :K]
-    wbig = torch.randint(-2, 3, (3 * N, K), generator=g).to(torch.bfloat16).cuda()
-    b = torch.randint(-4, 5, (N,), generator=g).to(torch.bfloat16).cuda()
-    ybig = torch.full((M + 7, N + 64), 7.0, dtype=torch.bfloat16, device="cuda")
-    rc = _lib.lib().ir_linear_fwd_ex(1, 0, M, N, K, x.data_ptr(), x.stride(0), wbig[N:2 * N].data_ptr(), K, b.data_ptr(),
-                                     ybig.data_ptr(), ybig.stride(0), 0, 1.0, ops.LIN_KERNELS["x_stationary_pp"], ops._stream())
-    _lib.check(rc, "ir_linear_fwd_ex")
-    torch.cuda.synchronize()
-    ref = (x.float() @ wbig[N:2 * N].float().T + b.float()).to(torch.bfloat16)
-    assert torch.equal(ybig[:M, :N], ref)
-    assert bool((ybig[:, N:] == 7.0).all()) and bool((ybig[M:] == 7.0).all())
-
-
 def test_linear_auto_choice_covers_every_projection_of_the_topology():
     """no projection of the SD-Turbo attention topology is left to a vendor GEMM"""
     from instantrestore_amd import ops

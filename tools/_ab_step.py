@@ -1,4 +1,4 @@
-"""same-box interleaved A/B of the bench step: usage _ab_step.py <switch> ; switch in {ref_stats, own_gemm}
+"""same-box interleaved A/B of the bench step: usage _ab_step.py <switch> ; switch in {ref_stats, own_gemm, x_stationary_rot, x_stationary_pp}
  ref_stats: AdaIN content statistics from the capture layer (round 3) vs re-read in every shared layer
  own_gemm : this library's GEMMs for every projection vs F.linear for the shapes the vendor GEMM served before round 3"""
 import os, sys, time
@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from instantrestore_amd import attn_processors as ap, ops
+ops.LIN_KERNELS = {**ops.LIN_KERNELS, **ops.LIN_KERNELS_DEV}   # ids 9 / 10 exist in development builds (IR_LIB_PATH)
 
 what = sys.argv[1] if len(sys.argv) > 1 else "ref_stats"
 dev = torch.device("cuda", 0)
@@ -20,9 +21,21 @@ def old_rule(x, w, b):   # rounds 1-2: own kernels for K <= 320 / 640 above 2^24
     return orig_supported(x, w, b) and ((k % 64 == 0 and k <= 320) or k == 640) and rows * w.shape[0] >= (1 << 24)
 
 
+orig_linear = ops.linear
+XS_VARIANT = ops.LIN_KERNELS.get(what, 0)
+
+
+def variant_linear(x, w, b=None, **kw):   # the K = 320 shapes the automatic choice gives to the X-stationary kernel -> the variant under test
+    if kw.get("kernel", 0) == 0 and w.shape[1] == 320 and ops.linear_kernel_for(x.numel() // 320, w.shape[0], 320, b is not None) == 1:
+        kw["kernel"] = XS_VARIANT
+    return orig_linear(x, w, b, **kw)
+
+
 def setmode(on):
     if what == "ref_stats":
         bench.REF_STATS["on"] = on
+    elif XS_VARIANT:
+        ops.linear = variant_linear if on else orig_linear
     else:
         ops.linear_supported = orig_supported if on else old_rule
 

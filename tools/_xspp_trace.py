@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from instantrestore_amd import ops
+ops.LIN_KERNELS = {**ops.LIN_KERNELS, **ops.LIN_KERNELS_DEV}   # ids 9 / 10 exist in development builds (IR_LIB_PATH)
 NS = int(os.environ.get("XSPP_STAMPS", "6"))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 960
 f32 = len(sys.argv) > 2 and sys.argv[2] == "fp32"

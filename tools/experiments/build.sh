@@ -7,6 +7,11 @@
 #   shared_attn_fwd_w64_dev.hip   the 64-row kernel WITH its PP template branch (variant 15), W64_TRACE / W64_PP_TRACE phase
 #                                 stamps and W64_ABL_* timing ablations - replaces csrc/shared_attn_fwd_w64.hip in this build
 #   linear_skinny_dev.hip    the X-stationary GEMM with LIN_TRACE / LIN_ABL_* - replaces csrc/linear_skinny.hip
+#   linear_xs_pp.hip         round 3: the K = 320 X-stationary GEMM with ping-pong wave groups (ir_linear_fwd_ex kernel id 9;
+#                            -DXSPP_TRACE=<block> phase stamps, -DXSPP_ABL=<bits> timing ablations)
+#   linear_xs_rot.hip        round 3: the same with a wave's two row blocks rotated, staging / stores between the MFMAs (id 10;
+#                            -DXSROT_TRACE=<block>).  Both bit-identical to the product kernel and no faster: the shape runs at
+#                            the board power cap (NOTES.md 9.6, profiles/r3_gemm_power.txt)
 # None of this is in the product library.  usage: tools/experiments/build.sh [-DW64_TRACE ...]; output: $IR_OUT
 # (default tools/experiments/libinstantrestore_hip_dev.so); use it with IR_LIB_PATH=<that file> and the tools/ scripts.
 set -euo pipefail
@@ -16,7 +21,7 @@ OUT="${IR_OUT:-${HERE}/libinstantrestore_hip_dev.so}"
 BUILD_DIR="${IR_BUILD_DIR:-${HERE}/build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 PRODUCT=(linear_tiled.hip shared_attn_fwd.hip shared_attn_fwd_pipe.hip attn_probs.hip adain.hip image_io.hip c_abi.hip)
-DEV=(shared_attn_fwd_w64_dev.hip linear_skinny_dev.hip shared_attn_fwd_sp.hip shared_attn_fwd_tp.hip shared_attn_fwd_pp.hip)
+DEV=(shared_attn_fwd_w64_dev.hip linear_skinny_dev.hip linear_xs_pp.hip linear_xs_rot.hip shared_attn_fwd_sp.hip shared_attn_fwd_tp.hip shared_attn_fwd_pp.hip)
 mkdir -p "${BUILD_DIR}"
 OBJS=(); pids=()
 for s in "${PRODUCT[@]}"; do

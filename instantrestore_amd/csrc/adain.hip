@@ -107,92 +107,6 @@ __global__ void __launch_bounds__(AT) adain_partial_kernel(const AdainKParams p)
   }
 }
 
-// Short token axes (the 16x16-token layers: one chunk per matrix, at most NM matrices): one workgroup per
-// (b, h) fetches the self matrix and all references up front (every load in flight at once), reduces them and
-// emits the affine - ONE launch instead of a streaming pass plus a finalize whose launch and memory
-// latencies, not their bytes, were most of the 30 us.  grid: (H, B).
-template <typename T, int NM>
-__global__ void __launch_bounds__(AT) adain_small_kernel(const AdainKParams p) {
-  using v8 = typename ElemTraits<T>::v8;
-  __shared__ float red[32][8][17];
-  __shared__ float stats[NM][128];   // per matrix: mean[64], M2[64]
-  const int h = blockIdx.x, b = blockIdx.y;
-  const int tid = threadIdx.x, slot = tid & 7, rs = tid >> 3;
-  constexpr int PER = ROWS / 32;
-  v8 xs[NM][PER];
-#pragma unroll
-  for (int j = 0; j < NM; ++j) {
-    const int jj = j <= p.N ? j : 0;   // unused slots re-read the self matrix (never reduced)
-    const T* base = jj == 0 ? (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh
-                            : (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)(jj - 1) * p.vr_sn + (int64_t)h * p.vr_sh;
-    const int64_t sl = jj == 0 ? p.vs_sl : p.vr_sl;
-    const int len = jj == 0 ? p.Ls : p.Lr;
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-      const int r = rs + it * 32;
-      xs[j][it] = *(const v8*)(base + (int64_t)(r < len ? r : len - 1) * sl + slot * 8);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NM; ++j) {
-    if (j > p.N) break;
-    const int len = j == 0 ? p.Ls : p.Lr;
-    float cnt = 0.f, K[8], s1[8], s2[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { K[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
-#pragma unroll
-    for (int it = 0; it < PER; ++it) {
-      if (rs + it * 32 < len) {
-        const f32x8 f = __builtin_convertvector(xs[j][it], f32x8);
-        if (cnt == 0.f) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) K[i] = f[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const float d = f[i] - K[i];
-          s1[i] += d;
-          s2[i] = __builtin_fmaf(d, d, s2[i]);
-        }
-        cnt += 1.f;
-      }
-    }
-    if (j > 0) __syncthreads();   // the previous matrix's merge has read `red`
-    {
-      float* o = &red[rs][slot][0];
-      o[0] = cnt;
-      const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        o[1 + i] = K[i] + s1[i] * inv;
-        o[9 + i] = s2[i] - s1[i] * s1[i] * inv;
-      }
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const int cs = tid >> 3, ci = tid & 7;
-      float n = 0.f, mean = 0.f, m2 = 0.f;
-      for (int k = 0; k < 32; ++k) {
-        const float* o = &red[k][cs][0];
-        chan_merge(n, mean, m2, o[0], o[1 + ci], o[9 + ci]);
-      }
-      stats[j][tid] = mean;
-      stats[j][64 + tid] = m2;
-    }
-  }
-  __syncthreads();
-  for (int i = tid; i < p.N * 64; i += AT) {
-    const int n = i >> 6, d = i & 63;
-    // torch.std default: unbiased (n-1); a single token gives 0/0 = NaN exactly like torch
-    const float sd_v = sqrtf(stats[0][64 + d] / (float)(p.Ls - 1)) + p.eps;
-    const float sd_x = sqrtf(stats[1 + n][64 + d] / (float)(p.Lr - 1)) + p.eps;
-    const float a = sd_v / sd_x;
-    const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
-    p.a[o] = a;
-    p.b[o] = stats[0][d] - stats[1 + n][d] * a;
-  }
-}
-
 // grid: (B*N*H); 64 threads = channels. Merges chunk partials, emits the affine.
 __global__ void __launch_bounds__(64) adain_finalize_kernel(const AdainKParams p) {
   const int d = threadIdx.x;
@@ -429,11 +343,9 @@ __global__ void __launch_bounds__(256) zero_refs_kernel(const ZeroRefsKParams p)
 }  // namespace
 
 hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s) {
-  if (p.nchunk == 1 && 1 + p.N <= 5 && p.B * p.H >= 128) {   // short axes, enough (b, h) pairs to fill the chip
-    if (dtype == 1) hipLaunchKernelGGL((adain_small_kernel<__bf16, 5>), dim3(p.H, p.B), dim3(AT), 0, s, p);
-    else hipLaunchKernelGGL((adain_small_kernel<_Float16, 5>), dim3(p.H, p.B), dim3(AT), 0, s, p);
-    return hipGetLastError();
-  }
+  // (round 3: a one-launch kernel for the 16x16-token layers - every matrix of a (b, h) pair fetched up front by ONE workgroup -
+  //  was 22.9 us against 11.1 us for the two launches below once the step is replayed from a hipGraph: five reductions and
+  //  their 32-step merges in sequence, on 160 workgroups; tools/gpu_adain_time.py)
   const dim3 grid(p.nchunk, p.H, p.B * (1 + p.N));
   if (dtype == 1) hipLaunchKernelGGL((adain_partial_kernel<__bf16>), grid, dim3(AT), 0, s, p);
   else hipLaunchKernelGGL((adain_partial_kernel<_Float16>), grid, dim3(AT), 0, s, p);

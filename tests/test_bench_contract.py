@@ -21,7 +21,7 @@ def test_bench_refuses_to_run_without_a_gpu():
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_fields():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
-                       capture_output=True, text=True, cwd=REPO, timeout=900)
+                       capture_output=True, text=True, cwd=REPO, timeout=900, env=dict(os.environ, IR_BENCH_POWER_SECONDS="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
@@ -38,6 +38,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in rf, k
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "shared_attn" in rf["kernel"]
+    pw = d["config"]["extras"]["power"]      # board power / shader clock beside a sustained run: readings, or the reason there are none
+    assert "error" in pw or (0 < pw["watts_avg"] <= 1.1 * pw["board_cap_watts"] and 0 < pw["sclk_mhz_avg"] <= pw["sclk_peak_mhz"] + 50)
+    if "error" not in pw:
+        assert abs(rf["at_measured_clock"]["frac_at_clock"] * rf["at_measured_clock"]["peak_at_clock"] - rf["achieved"]) < 1.0
 
 
 @pytest.mark.gpu

@@ -228,13 +228,29 @@ def kernel_class_breakdown(layers, B, N, steps):
             return r
         return w
 
+    # algorithmic work of every call beside its label: attention 4*B*Lq*Lkv*C flops, GEMM 2*M*N*K flops,
+    # AdaIN statistics the bytes of the V matrices the call reads once
+    work = {}
+
+    def note(label, flops=0.0, nbytes=0.0):
+        f, b = work.get(label, (0.0, 0.0))
+        work[label] = (f + flops, b + nbytes)
+        return label
+
+    def att_label(q, k, v, rk=None, rv=None, **kw):
+        lkv = (k.shape[1] if kw.get("include_self", True) or rk is None else 0) + (0 if rk is None else rk.shape[1] * rk.shape[2])
+        return note("attention L=%d %s" % (q.shape[1], "shared" if rk is not None else "capture"),
+                    flops=4.0 * q.shape[0] * q.shape[1] * lkv * q.shape[2])
+
+    def lin_label(x, w, b=None, **kw):
+        return note("projection GEMM K=%d" % w.shape[1], flops=2.0 * (x.numel() // x.shape[-1]) * w.shape[0] * w.shape[1])
+
     saved = (ops.shared_attention, ops.linear, ops.adain_stats, ops.adain_stats_cached, ops.token_stats)
-    ops.shared_attention = timed(saved[0], lambda q, k, v, rk=None, rv=None, **kw:
-                                 "attention L=%d %s" % (q.shape[1], "shared" if rk is not None else "capture"))
-    ops.linear = timed(saved[1], lambda x, w, b=None, **kw: "projection GEMM K=%d" % w.shape[1])
-    ops.adain_stats = timed(saved[2], lambda v, rv, **kw: "AdaIN statistics")
-    ops.adain_stats_cached = timed(saved[3], lambda v, m, sd, **kw: "AdaIN statistics")
-    ops.token_stats = timed(saved[4], lambda x, **kw: "AdaIN statistics")
+    ops.shared_attention = timed(saved[0], att_label)
+    ops.linear = timed(saved[1], lin_label)
+    ops.adain_stats = timed(saved[2], lambda v, rv, **kw: note("AdaIN statistics", nbytes=2.0 * (v.numel() + rv.numel())))
+    ops.adain_stats_cached = timed(saved[3], lambda v, m, sd, **kw: note("AdaIN statistics", nbytes=2.0 * v.numel()))
+    ops.token_stats = timed(saved[4], lambda x, **kw: note("AdaIN statistics", nbytes=2.0 * x.numel()))
     try:
         with torch.no_grad():
             for _ in range(steps):
@@ -246,7 +262,18 @@ def kernel_class_breakdown(layers, B, N, steps):
     for label, e0, e1 in rec:
         tot[label] = tot.get(label, 0.0) + e0.elapsed_time(e1)
     allms = sum(tot.values())
-    return {k: {"ms_per_step": round(v / steps, 4), "share": round(v / allms, 4)} for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+    out = {}
+    for k, v in sorted(tot.items(), key=lambda kv: -kv[1]):
+        row = {"ms_per_step": round(v / steps, 4), "share": round(v / allms, 4)}
+        f, b = work.get(k, (0.0, 0.0))
+        if f:
+            row["tflops"] = round(f / v / 1e9, 1)
+            row["frac_of_mfma_peak"] = round(f / v / 1e9 / 2500.0, 4)
+        if b:
+            row["gb_per_s"] = round(b / v / 1e6, 1)
+            row["frac_of_hbm_peak"] = round(b / v / 1e6 / 8000.0, 4)
+        out[k] = row
+    return out
 
 
 def _pmc_profile_name():

@@ -122,11 +122,12 @@ def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached
     procs = [ly["kv_attn"].processor for ly in layers]
     for p in procs:
         p.stop_after_capture = procs if ref_early_exit else None
-    # AdaIN content statistics (mean / std of every reference V) once per reference in the capture layer - when that does
-    # not lengthen the critical path: with the two UNets on two streams the CAPTURE stream is the longer one (9 layers over
-    # B*N token sets against 9 over B), and moving the statistics there costs +0.3 ms (profiles/r3_ab_step.txt); there the
-    # shared layers keep computing them (ir_adain_stats) in the main stream's slack
-    use_stats = bool(layers[0]["main_attn"].processor.use_adain) and REF_STATS["on"] and not two_streams
+    # AdaIN content statistics (mean / std of every reference V) once per reference, in the capture layer.  Round 4: they are
+    # the tail of that layer's q/k/v GEMM (ir_linear_fwd_stats: no pass over V), so they ride on the capture stream for free;
+    # with the tail off (attn_processors.FUSED_STATS = False, the round-3 A/B) the standalone pass would lengthen the capture
+    # stream - the longer one of the two - by 0.3 ms (profiles/r3_ab_step.txt) and the shared layers keep it instead
+    from instantrestore_amd import attn_processors as _ap_mod
+    use_stats = bool(layers[0]["main_attn"].processor.use_adain) and REF_STATS["on"] and (_ap_mod.FUSED_STATS or not two_streams)
     for p in procs:
         p.record_events = two_streams
         p.capture_stats = use_stats    # AdaIN content statistics once per reference, on the capture stream (kv_harvest)
@@ -245,19 +246,24 @@ def kernel_class_breakdown(layers, B, N, steps):
     def lin_label(x, w, b=None, **kw):
         return note("projection GEMM K=%d" % w.shape[1], flops=2.0 * (x.numel() // x.shape[-1]) * w.shape[0] * w.shape[1])
 
-    saved = (ops.shared_attention, ops.linear, ops.adain_stats, ops.adain_stats_cached, ops.token_stats)
+    saved = (ops.shared_attention, ops.linear, ops.adain_stats, ops.adain_stats_cached, ops.token_stats,
+             ops.adain_affine_from_partials, ops.token_stats_from_partials)
     ops.shared_attention = timed(saved[0], att_label)
     ops.linear = timed(saved[1], lin_label)
     ops.adain_stats = timed(saved[2], lambda v, rv, **kw: note("AdaIN statistics", nbytes=2.0 * (v.numel() + rv.numel())))
     ops.adain_stats_cached = timed(saved[3], lambda v, m, sd, **kw: note("AdaIN statistics", nbytes=2.0 * v.numel()))
     ops.token_stats = timed(saved[4], lambda x, **kw: note("AdaIN statistics", nbytes=2.0 * x.numel()))
+    # round 4: the statistics are the q/k/v GEMMs' tail (inside "projection GEMM"); what is left are the merges of the partials
+    ops.adain_affine_from_partials = timed(saved[5], lambda st, *a, **kw: note("AdaIN affine from GEMM partials", nbytes=4.0 * st.ws.numel()))
+    ops.token_stats_from_partials = timed(saved[6], lambda st, *a, **kw: note("AdaIN affine from GEMM partials", nbytes=4.0 * st.ws.numel()))
     try:
         with torch.no_grad():
             for _ in range(steps):
                 hot_path_step(layers, B, N, False, False)
         torch.cuda.synchronize()
     finally:
-        ops.shared_attention, ops.linear, ops.adain_stats, ops.adain_stats_cached, ops.token_stats = saved
+        (ops.shared_attention, ops.linear, ops.adain_stats, ops.adain_stats_cached, ops.token_stats,
+         ops.adain_affine_from_partials, ops.token_stats_from_partials) = saved
     tot = {}
     for label, e0, e1 in rec:
         tot[label] = tot.get(label, 0.0) + e0.elapsed_time(e1)

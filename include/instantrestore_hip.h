@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IR_ABI_VERSION 5
+#define IR_ABI_VERSION 6
 #define IR_HEAD_DIM 64
 
 typedef enum ir_status {
@@ -325,6 +325,41 @@ int ir_linear_fwd_ex(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int3
                      int32_t kernel, void* stream);
 /* kernel id (IR_LIN_*) the automatic choice makes for a shape, or -1 when no kernel covers it */
 int ir_linear_kernel_for(int64_t m, int32_t n, int32_t k, int32_t has_bias);
+
+/*
+ * ir_linear_fwd_stats - ir_linear_fwd_scaled that ALSO leaves the token statistics of output columns
+ * [stats_col0, stats_col0 + stats_cols) behind: the AdaIN statistics pass (attn_processors.py:9-10, :244-245) fused into
+ * the projection that produces V (ABI 6, round 4).
+ *
+ * The workgroup that has stored a (rows x 64-column) block of those columns re-reads it from its L2 and writes the block's
+ * partial statistics - mean[64] | M2[64], fp32, of the ROUNDED 16-bit outputs, the values the attention kernel will read -
+ * to stats_ws[(row_block * (stats_cols / 64) + head) * 128 ...], row blocks of ir_linear_stats_rows(m, n, k, has_bias)
+ * rows in row order.  For the V third of a fused q/k/v projection (stats_col0 = 2C, stats_cols = C) over token sets of
+ * L rows each (L % rows == 0) the partials of set s are blocks [s L / rows, (s + 1) L / rows): what
+ * ir_adain_affine_from_partials / ir_token_stats_from_partials merge.  Same arithmetic as ir_adain_stats' own partial pass
+ * (shifted single-pass sums, Chan merge); no pass over V, no extra launch.
+ *   stats_col0, stats_cols, n: multiples of 64; m % rows == 0, rows = ir_linear_stats_rows(...) > 0 (0: this shape's kernel
+ *   cannot emit them - use ir_adain_stats / ir_token_stats);  stats_ws: >= (m / rows) * (stats_cols / 64) * 512 bytes
+ */
+int ir_linear_stats_rows(int64_t m, int32_t n, int32_t k, int32_t has_bias);
+int ir_linear_fwd_stats(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                        int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
+                        int32_t stats_col0, int32_t stats_cols, float* stats_ws, size_t stats_ws_bytes, void* stream);
+/*
+ * ir_adain_affine_from_partials - the (a, b) of ir_adain_stats from those partials: one small launch per shared layer.
+ *   style_ws: partials of V_self from the shared layer's own q/k/v projection (B sets of len_self rows, style_rows per block);
+ *   content: EITHER content_ws / content_rows - partials of the reference V's from the K/V-capture layer's projection
+ *   (B * N sets of len_ref rows, set index b * N + n) - OR content_mean / content_std, fp32 (B, N, H, 64), std without eps
+ *   (ir_token_stats_from_partials, ir_token_stats: a per-identity cache); valid: optional int32 (B) on the device -
+ *   references n >= valid[b] were zero-filled (ir_zero_invalid_refs) and count with statistics (0, 0).
+ */
+int ir_adain_affine_from_partials(int32_t batch, int32_t heads, int32_t n_refs, int32_t len_self, int32_t len_ref,
+                                  const float* style_ws, int32_t style_rows, const float* content_ws, int32_t content_rows,
+                                  const float* content_mean, const float* content_std, const int32_t* valid, float eps,
+                                  float* a, float* b, void* stream);
+/* mean and unbiased std (no eps) of n_sets matrices of `len` rows from their partials: fp32 (n_sets, H, 64) each */
+int ir_token_stats_from_partials(int32_t n_sets, int32_t heads, int32_t len, const float* ws, int32_t rows, float* mean, float* std,
+                                 void* stream);
 
 /* library identity / diagnostics */
 int ir_abi_version(void);                  /* == IR_ABI_VERSION */

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # IR_LIB_PATH: load an alternative build of the same ABI (compiler-flag A/B experiments)
 LIB_PATH = os.environ.get("IR_LIB_PATH") or os.path.join(_HERE, "libinstantrestore_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 IR_DTYPE_F16, IR_DTYPE_BF16 = 0, 1
 IR_FLAG_INCLUDE_SELF, IR_FLAG_Q_PRESCALED, IR_FLAG_OUT_F32 = 1, 2, 4
@@ -70,6 +70,10 @@ SYMBOLS = {
     "ir_linear_fwd_scaled": (C.c_int, [i32, i32, i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, i32, f32, vp]),
     "ir_linear_fwd_ex": (C.c_int, [i32, i32, i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, i32, f32, i32, vp]),
     "ir_linear_kernel_for": (C.c_int, [i64, i32, i32, i32]),
+    "ir_linear_stats_rows": (C.c_int, [i64, i32, i32, i32]),
+    "ir_linear_fwd_stats": (C.c_int, [i32, i32, i64, i32, i32, vp, i64, vp, i64, vp, vp, i64, i32, f32, i32, i32, vp, C.c_size_t, vp]),
+    "ir_adain_affine_from_partials": (C.c_int, [i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, vp, vp, f32, vp, vp, vp]),
+    "ir_token_stats_from_partials": (C.c_int, [i32, i32, i32, vp, i32, vp, vp, vp]),
     "ir_zero_invalid_refs": (C.c_int, [i32, i32, i32, i32, vp, vp, i64, i64, i64, i64,
                                        vp, i64, i64, i64, i64, vp]),
 }

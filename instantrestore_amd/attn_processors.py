@@ -119,9 +119,14 @@ FUSED_CAST = True   # own GEMM: fp32 activations (autocast) are rounded to the c
 PRESCALE_Q = True   # own fused q/k/v GEMM: q leaves its epilogue as Q * attn.scale * log2(e) (still one rounding)
 
 
-def _project_qkv(attn, st: _Prepared):
+FUSED_STATS = True  # own fused q/k/v GEMM: the token statistics of its V third (AdaIN) are its workgroups' tail, no pass over V
+
+
+def _project_qkv(attn, st: _Prepared, want_stats: bool = False):
     """``to_q`` / ``to_k`` / ``to_v`` of the reference (attn_processors.py:222-230).  Returns
-    ``(q, k, v, q_prescaled)``.
+    ``(q, k, v, q_prescaled, v_stats)``; ``v_stats`` is ``None`` unless ``want_stats`` and the fused GEMM could leave
+    the partial token statistics of V behind (``ops.ColumnStats``: what ``adain`` needs of V, attn_processors.py:9-10,
+    :244-245, without a pass over it).
 
     Self-attention whose three projections are bias-free linear maps of equal shape - plain
     ``nn.Linear`` or peft LoRA wrappers in inference state (``lora_fold``) - runs them as ONE
@@ -140,11 +145,11 @@ def _project_qkv(attn, st: _Prepared):
     src = _kv_source(attn, st)
     tq, tk, tv = attn.to_q, attn.to_k, attn.to_v
     if st.encoder is not None or torch.is_grad_enabled():
-        return tq(st.hidden), tk(src), tv(src), False
+        return tq(st.hidden), tk(src), tv(src), False, None
     effs = [_lora.effective_linear(m) for m in (tq, tk, tv)]
     if any(e is None or e[0].bias is not None for e in effs) or \
             not (effs[0][0].weight.shape == effs[1][0].weight.shape == effs[2][0].weight.shape):
-        return tq(st.hidden), tk(src), tv(src), False
+        return tq(st.hidden), tk(src), tv(src), False, None
     dtype = _autocast_or(effs[0][0].weight, st.hidden)
     w = _lora.cached_weight(attn, "_ir_qkv_cache", (tq, tk, tv), dtype)
     c = w.shape[0] // 3
@@ -153,8 +158,16 @@ def _project_qkv(attn, st: _Prepared):
     if x.dtype != dtype and not (own and FUSED_CAST):
         x = x.to(dtype)
     presc = bool(PRESCALE_Q and c % 32 == 0 and own and _ops.tuning_supports_prescaled_q())
-    qkv = _ops.linear(x, w, None, scale_cols=c, col_scale=float(attn.scale) * LOG2E) if presc else _linear(x, w, None)
-    return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], presc
+    kw = dict(scale_cols=c, col_scale=float(attn.scale) * LOG2E) if presc else {}
+    vstats = None
+    if want_stats and FUSED_STATS and own and x.dim() == 3 and c % _ops.HEAD_DIM == 0:
+        # token statistics of the V third as the GEMM's tail: whole row blocks per token set (rows | L), whole heads
+        rows = _ops.linear_stats_rows(x.shape[0] * x.shape[1], 3 * c, w.shape[1], False)
+        if rows > 0 and x.shape[1] % rows == 0:
+            qkv, vstats = _ops.linear(x, w, None, stats=(2 * c, c), **kw)
+    if vstats is None:
+        qkv = _ops.linear(x, w, None, **kw) if presc else _linear(x, w, None)
+    return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], presc, vstats
 
 
 def _project_kv_only(attn, st: _Prepared):
@@ -193,6 +206,11 @@ def _project_out(attn, tokens: torch.Tensor) -> torch.Tensor:
         bias = _lora.cached_cast(attn, "_ir_out_bias_cache", bias, dtype)
     x = tokens if tokens.dtype == dtype else tokens.to(dtype)
     return _linear(x, w, bias)
+
+
+def _stats_cached(value: torch.Tensor, cstats, heads: int):
+    """AdaIN affine from cached content statistics, reading only V_self (``ir_adain_stats_cached``)"""
+    return _ops.adain_stats_cached(value, cstats[0], cstats[1], heads=heads)
 
 
 def _same_16bit(q: torch.Tensor, *others: Optional[torch.Tensor]) -> List[Optional[torch.Tensor]]:
@@ -238,13 +256,19 @@ class AttnProcessor(nn.Module):
         self.stream = None
         self.v_mean, self.v_std = None, None
 
-    def _stash_stats(self, attn):
+    def _stash_stats(self, attn, vstats=None):
         """mean and unbiased std over the tokens of every captured V, per (head, channel): the content statistics of
         ``adain`` (attn_processors.py:9-10) computed HERE, once per reference and on the capture stream, instead of in
-        every shared layer of every frame"""
-        if self.capture_stats and self.values.is_cuda:
-            m, sd = _ops.token_stats(self.values.unsqueeze(1), heads=attn.heads)      # (B*N, 1, H, 64) each
-            self.v_mean, self.v_std = m[:, 0], sd[:, 0]
+        every shared layer of every frame.  ``vstats``: the partials the q/k/v GEMM left behind (round 4: no pass over V,
+        one 64-thread-per-(set, head) merge); without them ``ir_token_stats`` reads V."""
+        if not self.capture_stats:
+            self.v_mean, self.v_std = None, None     # never hand a later harvest the statistics of an earlier capture
+        elif self.values.is_cuda:
+            if vstats is not None:
+                self.v_mean, self.v_std = _ops.token_stats_from_partials(vstats, self.values.shape[0], self.values.shape[1])
+            else:
+                m, sd = _ops.token_stats(self.values.unsqueeze(1), heads=attn.heads)      # (B*N, 1, H, 64) each
+                self.v_mean, self.v_std = m[:, 0], sd[:, 0]
 
     def _mark_ready(self):
         if self.keys.is_cuda:
@@ -264,9 +288,9 @@ class AttnProcessor(nn.Module):
             self._stash_stats(attn)
             self._mark_ready()
             raise ReferenceCaptureComplete()
-        query, key, value, presc = _project_qkv(attn, st)
+        query, key, value, presc, vstats = _project_qkv(attn, st, want_stats=bool(self.capture_stats))
         self.keys, self.values = key, value  # consumed in place by the shared layers: no copies
-        self._stash_stats(attn)
+        self._stash_stats(attn, vstats)
         self._mark_ready()
         _same_16bit(query, key, value)
         kw = {"q_prescaled": True} if presc else {}
@@ -330,12 +354,13 @@ class SharedAttnProcessor(nn.Module):
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                 ref_keys=None, ref_values=None, ref_events=None, ref_stats=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
-        query, key, value, presc = _project_qkv(attn, st)
+        shared = self.self_attn_idx is not None and ref_keys is not None and ref_values is not None
+        query, key, value, presc, vstats = _project_qkv(attn, st, want_stats=bool(shared and self.use_adain))
 
         ref_k = ref_v = None
         include_self = True
         affine = None
-        if self.self_attn_idx is not None and ref_keys is not None and ref_values is not None:
+        if shared:
             ref_k = ref_keys[self.self_attn_idx]
             ref_v = ref_values[self.self_attn_idx]
             cstats = ref_stats[self.self_attn_idx] if ref_stats is not None else None
@@ -354,8 +379,13 @@ class SharedAttnProcessor(nn.Module):
                 # style = this image's own post-projection V; content = each reference V.  With the content statistics
                 # handed over (``ref_stats``: computed once per identity by the K/V-capture layer, kv_harvest with_stats)
                 # only V_self is read here - 1/(N+1) of the bytes, the same (a, b) bit for bit
-                if cstats is not None:
-                    affine = _ops.adain_stats_cached(value, cstats[0], cstats[1], heads=attn.heads)
+                # Round 4: the style statistics arrive as the partials this layer's own q/k/v GEMM left behind (``vstats``):
+                # with them and the content statistics nothing of V is read here at all - one small launch
+                if cstats is not None and vstats is not None:
+                    affine = _ops.adain_affine_from_partials(vstats, value.shape[0], value.shape[1], ref_v.shape[1], ref_v.shape[2],
+                                                             content_mean=cstats[0], content_std=cstats[1])
+                elif cstats is not None:
+                    affine = _stats_cached(value, cstats, attn.heads)
                 else:
                     affine = _ops.adain_stats(value, ref_v, heads=attn.heads)
         _same_16bit(query, key, value, ref_k, ref_v)

@@ -212,6 +212,27 @@ __global__ void __launch_bounds__(256) adain_finalize_cached_kernel(const AdainK
   }
 }
 
+// The same without the LDS staging of the partials, for token axes whose chunk count does not fit it (len_self > ~30 000:
+// the 256x256-token layers of a 2048 px input): grid (B*H), 64 threads = channels, partials merged straight from memory.
+__global__ void __launch_bounds__(64) adain_finalize_cached_direct_kernel(const AdainKParams p) {
+  const int d = threadIdx.x;
+  const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
+  const int nch = (p.Ls + ROWS - 1) / ROWS;
+  const float* g = p.ws + (((int64_t)b * p.H + h) * p.nchunk) * 128;
+  float cn = 0.f, mean = 0.f, m2 = 0.f;
+  for (int c = 0; c < nch; ++c) {
+    const int rows = (c + 1) * ROWS <= p.Ls ? ROWS : p.Ls - c * ROWS;
+    chan_merge(cn, mean, m2, (float)rows, g[c * 128 + d], g[c * 128 + 64 + d]);
+  }
+  const float sd_v = sqrtf(m2 / (float)(p.Ls - 1)) + p.eps;
+  for (int n = 0; n < p.N; ++n) {
+    const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
+    const float a = sd_v / (p.cstd[o] + p.eps);
+    p.a[o] = a;
+    p.b[o] = mean - p.cmean[o] * a;
+  }
+}
+
 // One-chunk token axes (the 16x16-token class): one workgroup per (b, h) reads V_self and emits the affine. grid: (H, B).
 template <typename T>
 __global__ void __launch_bounds__(AT) adain_self_small_kernel(const AdainKParams p) {
@@ -382,7 +403,8 @@ hipError_t ir_launch_adain_stats_cached(const AdainKParams& p, int dtype, hipStr
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const size_t lds = (size_t)(p.nchunk * 128 + 128) * sizeof(float);
-  hipLaunchKernelGGL(adain_finalize_cached_kernel, dim3(p.B * p.H), dim3(256), lds, s, p);
+  if (lds <= 60 * 1024) hipLaunchKernelGGL(adain_finalize_cached_kernel, dim3(p.B * p.H), dim3(256), lds, s, p);
+  else hipLaunchKernelGGL(adain_finalize_cached_direct_kernel, dim3(p.B * p.H), dim3(64), 0, s, p);   // same merge order, same bits
   return hipGetLastError();
 }
 
@@ -446,5 +468,87 @@ hipError_t ir_launch_tensor2im(const void* x, void* out, int dtype, int64_t sb, 
   if (dtype == 0) hipLaunchKernelGGL((tensor2im_kernel<_Float16>), g, t, 0, s, (const _Float16*)x, (unsigned char*)out, sb, sc, sh, sw, B, C, H, W);
   else if (dtype == 1) hipLaunchKernelGGL((tensor2im_kernel<__bf16>), g, t, 0, s, (const __bf16*)x, (unsigned char*)out, sb, sc, sh, sw, B, C, H, W);
   else hipLaunchKernelGGL((tensor2im_kernel<float>), g, t, 0, s, (const float*)x, (unsigned char*)out, sb, sc, sh, sw, B, C, H, W);
+  return hipGetLastError();
+}
+
+// ---- round 4: AdaIN from the partial statistics the projection GEMMs leave behind (ir_colstats.h) -----------------------
+// The q/k/v projection of a shared layer stores the partials of V_self (style), the projection of the K/V-capture layer
+// those of every reference V (content), one (mean[64], M2[64]) per (row block, head), row blocks of `rows` tokens in
+// token order, so a matrix's partials are consecutive: ws[(set * len / rows + c) * H + h][128].  No pass over V is left.
+namespace {
+
+// merged (mean, M2) of one matrix's `nch` equal-sized partials for channel d; loads batched eight chunks ahead of the
+// serial Chan merges (the merge order is the chunk order: deterministic)
+__device__ __forceinline__ void merge_partials(const float* w, int64_t stride, int nch, float rows, int d, float& mean, float& m2) {
+  float cn = 0.f;
+  mean = 0.f; m2 = 0.f;
+  int c = 0;
+  for (; c + 8 <= nch; c += 8) {
+    float mu[8], mm[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { mu[i] = w[(c + i) * stride + d]; mm[i] = w[(c + i) * stride + 64 + d]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) chan_merge(cn, mean, m2, rows, mu[i], mm[i]);
+  }
+  for (; c < nch; ++c) chan_merge(cn, mean, m2, rows, w[c * stride + d], w[c * stride + 64 + d]);
+}
+
+// grid: (B*H); 256 threads = 4 matrices at a time x 64 channels.  LDS: (1 + N) x 128 floats.
+__global__ void __launch_bounds__(256) adain_affine_partials_kernel(const AdainPartialsKParams p) {
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  const int tid = threadIdx.x, d = tid & 63, g = tid >> 6;
+  const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
+  const int64_t hs = (int64_t)p.H * 128;
+  const int nmat = p.content_ws != nullptr ? 1 + p.N : 1;
+  for (int j = g; j < nmat; j += 4) {
+    float mean, m2;
+    if (j == 0) {
+      const int nch = p.Ls / p.style_rows;
+      merge_partials(p.style_ws + ((int64_t)b * nch) * hs + h * 128, hs, nch, (float)p.style_rows, d, mean, m2);
+    } else {
+      const int nch = p.Lr / p.content_rows;
+      merge_partials(p.content_ws + ((int64_t)(b * p.N + j - 1) * nch) * hs + h * 128, hs, nch, (float)p.content_rows, d, mean, m2);
+    }
+    psm[j * 128 + d] = mean;
+    psm[j * 128 + 64 + d] = m2;
+  }
+  __syncthreads();
+  const int nvalid = p.valid != nullptr ? p.valid[b] : p.N;
+  for (int i = tid; i < p.N * 64; i += 256) {
+    const int n = i >> 6, dd = i & 63;
+    const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + dd;
+    float mu_x, sd_x;
+    if (n >= nvalid) { mu_x = 0.f; sd_x = 0.f; }     // zero-filled reference (pix2pix_turbo.py:269-273): statistics (0, 0)
+    else if (p.content_ws != nullptr) { mu_x = psm[(1 + n) * 128 + dd]; sd_x = sqrtf(psm[(1 + n) * 128 + 64 + dd] / (float)(p.Lr - 1)); }
+    else { mu_x = p.cmean[o]; sd_x = p.cstd[o]; }
+    const float sd_v = sqrtf(psm[64 + dd] / (float)(p.Ls - 1)) + p.eps;
+    const float a = sd_v / (sd_x + p.eps);
+    p.a[o] = a;
+    p.b[o] = psm[dd] - mu_x * a;
+  }
+}
+
+// grid: (nsets*H); 64 threads.  mean / unbiased std of every matrix from its partials.
+__global__ void __launch_bounds__(64) token_stats_partials_kernel(const float* ws, int rows, int H, int len, float* mean_out, float* std_out) {
+  const int d = threadIdx.x;
+  const int h = blockIdx.x % H, set = blockIdx.x / H;
+  const int nch = len / rows;
+  float mean, m2;
+  merge_partials(ws + ((int64_t)set * nch) * H * 128 + h * 128, (int64_t)H * 128, nch, (float)rows, d, mean, m2);
+  const int64_t o = ((int64_t)set * H + h) * 64 + d;
+  mean_out[o] = mean;
+  std_out[o] = sqrtf(m2 / (float)(len - 1));
+}
+
+}  // namespace
+
+hipError_t ir_launch_adain_affine_partials(const AdainPartialsKParams& p, hipStream_t s) {
+  const size_t lds = (size_t)(1 + p.N) * 128 * sizeof(float);
+  hipLaunchKernelGGL(adain_affine_partials_kernel, dim3(p.B * p.H), dim3(256), lds, s, p);
+  return hipGetLastError();
+}
+
+hipError_t ir_launch_token_stats_partials(const float* ws, int rows, int nsets, int H, int len, float* mean, float* std, hipStream_t s) {
+  hipLaunchKernelGGL(token_stats_partials_kernel, dim3(nsets * H), dim3(64), 0, s, ws, rows, H, len, mean, std);
   return hipGetLastError();
 }

@@ -17,9 +17,15 @@ for s in "${SRCS[@]}"; do
   extra=()
   # the 64-row kernels need scalar (single-issue) fp32 code where the SLP vectoriser would form v_pk_* operations
   [[ "$s" == shared_attn_fwd_w64.hip ]] && extra+=(-fno-slp-vectorize)
-  "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function "${extra[@]}" "$@" -c "$s" -o "$o" &
+  # resource remarks (registers, spills, scratch per kernel) go to <build dir>/<source>.remarks: tools/check_resources.py reads them
+  "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage "${extra[@]}" "$@" -c "$s" -o "$o" 2> "${BUILD_DIR}/${s%.hip}.remarks" &
   pids+=($!)
 done
-for p in "${pids[@]}"; do wait "$p"; done
+fail=0
+for p in "${pids[@]}"; do wait "$p" || fail=1; done
+if [[ $fail != 0 ]]; then grep -h -v "Rpass-analysis" "${BUILD_DIR}"/*.remarks >&2 || true; echo "build.sh: compilation failed" >&2; exit 1; fi
+grep -h -E "warning|error" "${BUILD_DIR}"/*.remarks >&2 || true
+# kernels that keep asm-issued loads in C++ variables must not spill: fail the build if they do
+python3 "${HERE}/../../tools/check_resources.py" "${BUILD_DIR}"
 "${HIPCC}" --offload-arch=gfx950 -shared -fPIC "${OBJS[@]}" -o "${OUT}"
 echo "built ${OUT}"

@@ -225,7 +225,6 @@ int ir_adain_stats_cached(int32_t dtype, int32_t batch, int32_t heads, int32_t l
   p.ws = (float*)workspace; p.a = a; p.b = b;
   p.B = batch; p.H = heads; p.Ls = len_self; p.N = n_refs; p.Lr = len_self;
   p.nchunk = adain_nchunk(len_self, len_self);
-  if ((size_t)(p.nchunk * 128 + 128) * sizeof(float) > 60 * 1024) return fail(IR_ERR_UNSUPPORTED, "len_self %d: too many chunks", len_self);
   p.eps = eps;
   p.cmean = content_mean; p.cstd = content_std;
   const hipError_t e = ir_launch_adain_stats_cached(p, dtype, (hipStream_t)stream);
@@ -414,9 +413,72 @@ int ir_linear_kernel_for(int64_t m, int32_t n, int32_t k, int32_t has_bias) {
   return IR_LIN_TILED_FIRST + ir_linear_tiled_pick(m, n);
 }
 
+static int linear_fwd_impl(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                           int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
+                           int32_t kernel, int32_t st_col0, int32_t st_cols, float* st_ws, size_t st_ws_bytes, void* stream);
+
 int ir_linear_fwd_ex(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                      int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
                      int32_t kernel, void* stream) {
+  return linear_fwd_impl(dtype, x_is_f32, m, n, k, x, x_ld, w, w_ld, bias, y, y_ld, scale_cols, col_scale, kernel, 0, 0, nullptr, 0, stream);
+}
+
+static int stats_rows_of(int kernel) {   // every projection kernel gives a wave 64 rows of Y: the statistics block
+  if (kernel == IR_LIN_X_STATIONARY) return 64;
+  if (kernel >= IR_LIN_TILED_FIRST && kernel < IR_LIN_TILED_FIRST + IR_LIN_TILE_COUNT) return 64;
+  return 0;
+}
+
+int ir_linear_stats_rows(int64_t m, int32_t n, int32_t k, int32_t has_bias) {
+  if (m <= 0 || n <= 0 || k <= 0 || (n % 64) != 0) return 0;
+  const int rows = stats_rows_of(ir_linear_kernel_for(m, n, k, has_bias));
+  return (rows > 0 && (m % rows) == 0) ? rows : 0;
+}
+
+int ir_linear_fwd_stats(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                        int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
+                        int32_t stats_col0, int32_t stats_cols, float* stats_ws, size_t stats_ws_bytes, void* stream) {
+  if (stats_ws == nullptr) return fail(IR_ERR_INVALID_ARG, "stats_ws is NULL (use ir_linear_fwd_scaled for a call without statistics)");
+  return linear_fwd_impl(dtype, x_is_f32, m, n, k, x, x_ld, w, w_ld, bias, y, y_ld, scale_cols, col_scale, IR_LIN_AUTO, stats_col0, stats_cols,
+                         stats_ws, stats_ws_bytes, stream);
+}
+
+int ir_adain_affine_from_partials(int32_t batch, int32_t heads, int32_t n_refs, int32_t len_self, int32_t len_ref,
+                                  const float* style_ws, int32_t style_rows, const float* content_ws, int32_t content_rows,
+                                  const float* content_mean, const float* content_std, const int32_t* valid, float eps,
+                                  float* a, float* b, void* stream) {
+  if (batch <= 0 || heads <= 0 || n_refs <= 0 || len_self <= 0 || len_ref <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (!style_ws || !a || !b) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  if (style_rows <= 0 || (len_self % style_rows) != 0) return fail(IR_ERR_INVALID_ARG, "len_self %d is not a multiple of style_rows %d", len_self, style_rows);
+  if (content_ws != nullptr) {
+    if (content_rows <= 0 || (len_ref % content_rows) != 0) return fail(IR_ERR_INVALID_ARG, "len_ref %d is not a multiple of content_rows %d", len_ref, content_rows);
+  } else if (!content_mean || !content_std) {
+    return fail(IR_ERR_INVALID_ARG, "content statistics: either content_ws or content_mean + content_std");
+  }
+  if ((size_t)(1 + n_refs) * 128 * sizeof(float) > 60 * 1024) return fail(IR_ERR_UNSUPPORTED, "n_refs %d: too many references", n_refs);
+  AdainPartialsKParams p;
+  memset(&p, 0, sizeof(p));
+  p.style_ws = style_ws; p.content_ws = content_ws; p.cmean = content_mean; p.cstd = content_std; p.valid = valid;
+  p.a = a; p.b = b; p.B = batch; p.H = heads; p.N = n_refs; p.Ls = len_self; p.Lr = len_ref;
+  p.style_rows = style_rows; p.content_rows = content_ws != nullptr ? content_rows : 1; p.eps = eps;
+  const hipError_t e = ir_launch_adain_affine_partials(p, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "adain_affine_partials launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
+int ir_token_stats_from_partials(int32_t n_sets, int32_t heads, int32_t len, const float* ws, int32_t rows, float* mean, float* std,
+                                 void* stream) {
+  if (n_sets <= 0 || heads <= 0 || len <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
+  if (!ws || !mean || !std) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
+  if (rows <= 0 || (len % rows) != 0) return fail(IR_ERR_INVALID_ARG, "len %d is not a multiple of rows %d", len, rows);
+  const hipError_t e = ir_launch_token_stats_partials(ws, rows, n_sets, heads, len, mean, std, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "token_stats_partials launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
+static int linear_fwd_impl(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
+                           int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
+                           int32_t kernel, int32_t st_col0, int32_t st_cols, float* st_ws, size_t st_ws_bytes, void* stream) {
   if (scale_cols < 0 || scale_cols > n || (scale_cols % 32) != 0) return fail(IR_ERR_INVALID_ARG, "scale_cols %d: a multiple of 32 in [0, N]", scale_cols);
   if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d: fp16 (0) / bf16 (1)", dtype);
   if (!x || !w || !y) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
@@ -452,6 +514,16 @@ int ir_linear_fwd_ex(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int3
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.x_ld = x_ld; p.w_ld = w_ld; p.y_ld = y_ld;
   p.M = (int32_t)m; p.N = n; p.K = k; p.nsplit = 1;
   p.scale_cols = scale_cols; p.col_scale = col_scale; p.x_f32 = x_is_f32 ? 1 : 0;
+  p.st_ws = nullptr; p.st_col0 = 0; p.st_cols = 0;
+  if (st_ws != nullptr) {   // token statistics of columns [st_col0, st_col0 + st_cols) as the kernel's tail
+    const int rows = stats_rows_of(kernel);
+    if (st_col0 < 0 || st_cols <= 0 || (st_col0 % 64) != 0 || (st_cols % 64) != 0 || st_col0 + st_cols > n || (n % 64) != 0)
+      return fail(IR_ERR_INVALID_ARG, "statistics columns [%d, %d + %d): whole heads (multiples of 64) inside N = %d, N %% 64 == 0", st_col0, st_col0, st_cols, n);
+    if (rows <= 0 || (m % rows) != 0) return fail(IR_ERR_UNSUPPORTED, "statistics tail: M = %lld is not a multiple of the kernel's %d-row blocks (ir_linear_stats_rows)", (long long)m, rows);
+    const size_t need = (size_t)(m / rows) * (size_t)(st_cols / 64) * 128 * sizeof(float);
+    if (st_ws_bytes < need) return fail(IR_ERR_WORKSPACE, "stats_ws %zu < %zu bytes", st_ws_bytes, need);
+    p.st_ws = st_ws; p.st_col0 = st_col0; p.st_cols = st_cols;
+  }
   const hipError_t e =
 #ifdef IR_ABLATIONS
       kernel == IR_LIN_X_STATIONARY_PP    ? ir_launch_linear_xs_pp(p, dtype, (hipStream_t)stream)

@@ -63,6 +63,17 @@ static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// Lanes of ONE wave exchanging data through LDS (the GEMM epilogues: 16-bit rows written in the MFMA layout, read back as
+// whole 16-byte pieces of other lanes' rows) rely on the hardware executing a wave's LDS operations in order - and on the
+// COMPILER keeping them in order, which the language does not promise: to hipcc every lane is a thread of its own, and a
+// thread that executed no store between two loads of one address may have the second load forwarded from the first.  Round
+// 4: an unrelated edit of the 256 x 256 epilogue (whose staging writes sit under a lane-divergent `if`) made hipcc do
+// exactly that - rows 16-31 of every 32-row block came out as copies of rows 0-15, deterministically
+// (tests/test_gpu_linear.py).  ir_wave_lds_fence() goes between such writes and reads, both ways: a compiler barrier over
+// memory (no instruction; the hardware order is already there).  The staging reads also go through may_alias types.
+static __device__ __forceinline__ void ir_wave_lds_fence() { asm volatile("" ::: "memory"); }
+typedef u32x4 __attribute__((may_alias)) u32x4_alias;
+typedef f32x4 __attribute__((may_alias)) f32x4_alias;
 
 // 3-input max in one VALU op. Plain fmaxf() chains make hipcc canonicalise every MFMA output
 // first (a v_max_f32 x,x,x per element); the asm form takes the raw registers.

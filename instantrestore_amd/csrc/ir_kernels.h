@@ -118,6 +118,20 @@ hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_token_stats(const AdainKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_adain_stats_cached(const AdainKParams& p, int dtype, hipStream_t s);
+// round 4: the affine / the plain token statistics from the partials the projection GEMMs leave behind (ir_colstats.h)
+struct AdainPartialsKParams {
+  const float* style_ws;     // partials of V_self: [(b * Ls / style_rows + c)][H][128]
+  const float* content_ws;   // partials of the reference V's: [((b * N + n) * Lr / content_rows + c)][H][128], or nullptr
+  const float* cmean;        // ... then the finished content statistics (B, N, H, 64): mean, unbiased std (no eps)
+  const float* cstd;
+  const int32_t* valid;      // optional (B): references n >= valid[b] were zero-filled: statistics (0, 0)
+  float* a;
+  float* b;
+  int B, H, N, Ls, Lr, style_rows, content_rows;
+  float eps;
+};
+hipError_t ir_launch_adain_affine_partials(const AdainPartialsKParams& p, hipStream_t s);
+hipError_t ir_launch_token_stats_partials(const float* ws, int rows, int nsets, int H, int len, float* mean, float* std, hipStream_t s);
 hipError_t ir_launch_adain_apply(const AdainApplyKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_zero_refs(const ZeroRefsKParams& p, hipStream_t s);
 hipError_t ir_launch_tensor2im(const void* x, void* out, int dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw,
@@ -161,6 +175,10 @@ struct LinearKParams {
   int32_t x_f32;        // x is fp32 (x_ld in fp32 elements): cast to the 16-bit type while loading the resident fragments
   int32_t scale_cols;   // output columns [0, scale_cols) are multiplied by col_scale in fp32 before the rounding
   float col_scale;      // (scale_cols % 32 == 0; 0 = none): the softmax scale * log2(e) on the q third of a fused q/k/v
+  // round 4: token statistics of a column range (the V third of a fused q/k/v output) as the kernel's tail (ir_colstats.h):
+  // one (mean[64], M2[64]) partial per (64-row block, head); ws == nullptr: off
+  float* st_ws;
+  int32_t st_col0, st_cols;
 };
 hipError_t ir_launch_linear_skinny(const LinearKParams& p, int dtype, hipStream_t s);
 #ifdef IR_ABLATIONS   // development builds (tools/experiments/build.sh): two other schedules of the K = 320 case, kernel ids 9 and 10

@@ -13,6 +13,7 @@
 #include <type_traits>
 
 #include "ir_common.h"
+#include "ir_colstats.h"
 #include "ir_kernels.h"
 
 namespace {
@@ -117,6 +118,7 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
   // 64-B half lines per chunk the Y stream ran at 2.3 TB/s - each line was written in two halves an iteration apart.)
   unsigned char* tb = tbuf + wid * (64 * TPITCH);
   auto stage_block = [&](const f32x16& acc, int rbase, int n0, int half) {
+    ir_wave_lds_fence();   // these writes land on rows other lanes may just have read (ir_common.h)
     const float cs = n0 < p.scale_cols ? p.col_scale : 1.0f;   // leading columns scaled in fp32 before the one rounding
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -136,15 +138,17 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
   // s_waitcnt arithmetic of the main loop counts them
   const int row0 = mb * NT + wid * 64;
   auto store_full = [&](int j, int n0) {   // 8 rows x 128 B: one of the eight stores of a finished chunk PAIR
+    ir_wave_lds_fence();                   // rows staged by other lanes (ir_common.h)
     const int r = 8 * j + (lane >> 3);
-    const u32x4 v = *(const u32x4*)(tb + r * TPITCH + (lane & 7) * 16);
+    const u32x4 v = *(const u32x4_alias*)(tb + r * TPITCH + (lane & 7) * 16);
     const int row = row0 + r;
     T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 7) * 8;
     *(u32x4*)yp = v;
   };
   auto store_half = [&](int j, int n0) {   // 16 rows x 64 B (left half of the tile): a range's odd last chunk
+    ir_wave_lds_fence();
     const int r = 16 * j + (lane >> 2);
-    const u32x4 v = *(const u32x4*)(tb + r * TPITCH + (lane & 3) * 16);
+    const u32x4 v = *(const u32x4_alias*)(tb + r * TPITCH + (lane & 3) * 16);
     const int row = row0 + r;
     T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 3) * 8;
     *(u32x4*)yp = v;
@@ -207,6 +211,15 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
 #pragma unroll
     for (int j = 0; j < 4; ++j) store_half(j, (c_end - 1) * NCH);
   }
+  // ---- tail (round 4): token statistics of the V columns this wave has just written (ir_colstats.h) -----------------
+  if (p.st_ws != nullptr) {
+    int head_lo, head_hi;
+    ir_stats_heads(p.st_col0, p.st_cols, c_begin * NCH, c_end * NCH, head_lo, head_hi);   // column ranges are whole heads here
+    if (head_lo < head_hi) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of its 64 rows have left
+      ir_wave_col_stats<T, 5>((const T*)p.y, p.y_ld, row0, head_lo, head_hi, p.st_ws, p.st_col0, p.st_cols);
+    }
+  }
 }
 
 // K = 640 (the 32x32-token layer class): 64 rows of X no longer fit one wave's registers, so the contraction
@@ -237,7 +250,8 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
 
   const int mb = blockIdx.x / p.nsplit, sp = blockIdx.x - mb * p.nsplit;
   const int nchunks = p.N / NCH;
-  const int c_begin = (int)(((long)nchunks * sp) / p.nsplit), c_end = (int)(((long)nchunks * (sp + 1)) / p.nsplit);
+  const int unit = p.st_ws != nullptr ? 2 : 1, nu = nchunks / unit;   // with the statistics tail: ranges of whole heads (64 columns)
+  const int c_begin = unit * (int)(((long)nu * sp) / p.nsplit), c_end = unit * (int)(((long)nu * (sp + 1)) / p.nsplit);
   if (c_begin >= c_end) return;
 
   // ---- this wave's half of the X rows: resident for the whole kernel -------------------------------
@@ -309,7 +323,7 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
   // in the same LDS region (this wave's reads of it are complete before its writes: LDS operations of a wave execute in order)
   auto finish_tile = [&](f32x16& a, f32x16& b, int par, int n0) {
     unsigned char* r = rtile(par);
-    auto rd = [&](int q) { return *(const IR_LDS f32x4*)(IR_LDS unsigned char*)(r + lane * 16 + q * 1024); };
+    auto rd = [&](int q) -> f32x4 { return *(const IR_LDS f32x4_alias*)(IR_LDS unsigned char*)(r + lane * 16 + q * 1024); };   // may_alias: these reads must stay ahead of the 16-bit writes below
     auto bias4 = [&](int g) {
       f32x4 f = {0.f, 0.f, 0.f, 0.f};
       if (p.bias != nullptr) {
@@ -326,6 +340,7 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
 #pragma unroll
     for (int g = 0; g < 4; ++g) pa[g] = rd(g);
     pb0 = rd(4);
+    ir_wave_lds_fence();   // the 16-bit writes below land on partial quads other lanes have just read
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 bz = bias4(g);
@@ -338,6 +353,7 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
     pb[0] = pb0;
 #pragma unroll
     for (int g = 1; g < 4; ++g) pb[g] = rd(4 + g);
+    ir_wave_lds_fence();
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const f32x4 bz = bias4(g);
@@ -349,8 +365,9 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
   };
   const int row0 = mb * 256 + rb * 64;
   auto store_part = [&](int j, int par, int n0) {   // 16 rows x 64 B of the staged tile
+    ir_wave_lds_fence();
     const int rr = 16 * j + (lane >> 2);
-    const u32x4 v = *(const u32x4*)(rtile(par) + rr * TPITCH + (lane & 3) * 16);
+    const u32x4 v = *(const u32x4_alias*)(rtile(par) + rr * TPITCH + (lane & 3) * 16);
     const int row = row0 + rr;
     T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 3) * 8;
     *(u32x4*)yp = v;
@@ -411,6 +428,15 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
 #pragma unroll
     for (int j = 0; j < 4; ++j) store_part(j, par, n0);
   }
+  // ---- tail (round 4): token statistics of the V columns this wave has just written (ir_colstats.h) -----------------
+  if (p.st_ws != nullptr && kh == 0) {
+    int head_lo, head_hi;
+    ir_stats_heads(p.st_col0, p.st_cols, c_begin * NCH, c_end * NCH, head_lo, head_hi);   // the launcher aligns column ranges to 64 then
+    if (head_lo < head_hi) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ir_wave_col_stats<T, 5>((const T*)p.y, p.y_ld, row0, head_lo, head_hi, p.st_ws, p.st_col0, p.st_cols);
+    }
+  }
 }
 
 template <typename T, int KS, bool BIAS, int NW>
@@ -458,7 +484,7 @@ hipError_t launch(const LinearKParams& p0, hipStream_t s) {
   const int nchunks = p.N / NCH;
   if (p.K == 640) {   // contraction split over two waves, one 8-wave workgroup per CU
     int nsplit = (256 + mblocks - 1) / mblocks;
-    if (nsplit > nchunks) nsplit = nchunks;
+    if (nsplit > nchunks / (p.st_ws != nullptr ? 2 : 1)) nsplit = nchunks / (p.st_ws != nullptr ? 2 : 1);
     if (nsplit < 1) nsplit = 1;
     p.nsplit = nsplit;
     constexpr int KSH = 5;

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "ir_common.h"
+#include "ir_colstats.h"
 #include "ir_kernels.h"
 
 namespace {
@@ -238,13 +239,25 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) linear_tiled_kernel(const Lin
         }
       }
     }
+    ir_wave_lds_fence();   // the reads below fetch what OTHER lanes have just written
+    // round 4: the finished 16-bit rows pass through the lanes here, eight columns of row 8 j + (lane >> 3) each - the shape
+    // the token statistics of a V head are accumulated in (ir_colstats.h): no load, no pass over V
+    const int st_head = (ncol0 - p.st_col0) >> 6;
+    const bool st_on = p.st_ws != nullptr && ncol0 >= p.st_col0 && st_head < (p.st_cols >> 6) && row_base < p.M;   // wave-uniform
+    ColStatsAcc sacc;
 #pragma unroll
     for (int j = 0; j < MI * 4; ++j) {
       const int r = 8 * j + (lane >> 3);
-      const u32x4 v = *(const u32x4*)(tb + r * kTiledPitch + (lane & 7) * 16);
+      const u32x4 v = *(const u32x4_alias*)(tb + r * kTiledPitch + (lane & 7) * 16);
       const int row = row_base + r;
       if (row < p.M) *(u32x4*)((T*)p.y + (int64_t)row * p.y_ld + ncol0 + (lane & 7) * 8) = v;
+      if (st_on) {
+        if (j == 0) ir_stats_first<T>(sacc, v);
+        else ir_stats_add<T>(sacc, v);
+      }
     }
+    ir_wave_lds_fence();   // ... and the next 64-column group's writes land on what other lanes have just read
+    if (st_on) ir_stats_finish(sacc, p.st_ws + ((int64_t)(row_base / kStatsRows) * (p.st_cols >> 6) + st_head) * 128);
   }
 }
 
@@ -432,6 +445,10 @@ __global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKPa
 #pragma unroll
           for (int g = 0; g < 4; ++g) bvs[n2][g] = v4{0, 0, 0, 0};
       }
+      // round 4: token statistics of a V head from the finished rows on their way out (ir_colstats.h; see the other kernel)
+      const int st_head = (ncol0 - p.st_col0) >> 6;
+      const bool st_on = p.st_ws != nullptr && ncol0 >= p.st_col0 && st_head < (p.st_cols >> 6) && (em0 + wm * (MI * 32)) < p.M;
+      ColStatsAcc sacc;
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -449,15 +466,22 @@ __global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKPa
               }
             }
           }
+          ir_wave_lds_fence();   // every lane reads rows that the sixteen staging lanes have just written (ir_common.h)
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int r = 8 * j + (lane >> 3);
-            const u32x4 v = *(const u32x4*)(tb + r * kTiledPitch + (lane & 7) * 16);
+            const u32x4 v = *(const u32x4_alias*)(tb + r * kTiledPitch + (lane & 7) * 16);
             const int row = em0 + wm * (MI * 32) + mi * 32 + half * 16 + r;
             if (row < p.M) *(u32x4*)((T*)p.y + (int64_t)row * p.y_ld + ncol0 + (lane & 7) * 8) = v;
+            if (st_on) {
+              if (mi == 0 && half == 0 && j == 0) ir_stats_first<T>(sacc, v);
+              else ir_stats_add<T>(sacc, v);
+            }
           }
+          ir_wave_lds_fence();   // the next pass overwrites the rows just read
         }
       }
+      if (st_on) ir_stats_finish(sacc, p.st_ws + ((int64_t)((em0 + wm * (MI * 32)) / kStatsRows) * (p.st_cols >> 6) + st_head) * 128);
     }
   };
 

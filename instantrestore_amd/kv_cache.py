@@ -46,10 +46,20 @@ class ReferenceKVCache:
             return self._store[identity]
         self.misses += 1
         res = compute()
+        if not isinstance(res, (tuple, list)) or len(res) not in (2, 3):
+            # harvest_reference_kv(with_events=True) returns (keys, values, events[, stats]): events are not cacheable and
+            # must not be mistaken for statistics - accept the two documented forms only
+            raise ValueError("compute() must return (keys, values) or (keys, values, stats); harvest with with_events=False")
         keys, values = res[0], res[1]
         stats = res[2] if len(res) > 2 else None
         if len(keys) != len(values) or any(k.shape[0] != 1 or k.shape != v.shape for k, v in zip(keys, values)):
             raise ValueError("compute() must return matching lists of (1, N, L, C) tensors")
+        if stats is not None:
+            def _is_stat(st):
+                return st is None or (isinstance(st, (tuple, list)) and len(st) == 2 and
+                                      all(isinstance(t, torch.Tensor) and t.dtype == torch.float32 and t.dim() == 4 and t.shape[0] == 1 for t in st))
+            if len(stats) != len(keys) or not all(_is_stat(st) for st in stats):
+                raise ValueError("stats must be a per-layer list of None or (mean, std) fp32 tensors of shape (1, N, H, 64)")
         # compact copies: the harvested tensors are strided views of the capture layers' fused (B*N, L, 3C) projection
         # output - caching the views would pin that whole buffer (dead Q third, every other identity of the batch) per
         # entry and eviction would free nothing.  One entry = 2 * 9 layers * N * L * C * 2 bytes.
@@ -70,7 +80,11 @@ class ReferenceKVCache:
         n_layers = len(entries[0][0])
         keys = [torch.cat([e[0][l] for e in entries], dim=0) for l in range(n_layers)]
         values = [torch.cat([e[1][l] for e in entries], dim=0) for l in range(n_layers)]
-        if all(len(e) > 2 for e in entries):
+        with_stats = [len(e) > 2 for e in entries]
+        if any(with_stats) and not all(with_stats):
+            raise ValueError("assemble(): some of these identities were cached with AdaIN content statistics and some without; "
+                             "cache them the same way (the statistics would otherwise be dropped silently)")
+        if all(with_stats):
             stats = [None if any(e[2][l] is None for e in entries) else
                      (torch.cat([e[2][l][0] for e in entries], dim=0), torch.cat([e[2][l][1] for e in entries], dim=0))
                      for l in range(n_layers)]

@@ -122,24 +122,31 @@ def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, times
     thrown away by the inference caller (``inference/test.py:100`` keeps only the K/V lists), so its
     forward can stop at the last K/V-capturing layer - after ``to_k`` / ``to_v`` of that layer, before its
     attention, its out projection and everything downstream.  The harvested lists are identical."""
-    if with_stats:
-        enable_ref_stats(original_unet, True)
-    if not early_exit:
-        original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
-        return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats)
     procs = [p for p in original_unet.attn_processors.values() if type(p) in [_ap.AttnProcessor]]
     if not procs:
         raise RuntimeError("no AttnProcessor on this UNet: call register_attention_processor_kv_unet first")
-    for p in procs:                          # whichever capturing layer runs last stops the forward
-        p.reset()
-        p.stop_after_capture = procs
+    # the capture layers compute the content statistics for THIS call iff it asks for them; whatever the caller had set
+    # with enable_ref_stats comes back afterwards (a with_stats=True call must not leave every later capture paying for them)
+    saved_stats = [p.capture_stats for p in procs]
+    for p in procs:
+        p.capture_stats = bool(with_stats) or p.capture_stats
     try:
-        original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
-    except _ap.ReferenceCaptureComplete:
-        pass
-    else:
-        raise RuntimeError("early exit armed but the capturing layers did not all run")
+        if not early_exit:
+            original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
+            return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats)
+        for p in procs:                          # whichever capturing layer runs last stops the forward
+            p.reset()
+            p.stop_after_capture = procs
+        try:
+            original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
+        except _ap.ReferenceCaptureComplete:
+            pass
+        else:
+            raise RuntimeError("early exit armed but the capturing layers did not all run")
+        finally:
+            for p in procs:
+                p.stop_after_capture = None
+        return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats)
     finally:
-        for p in procs:
-            p.stop_after_capture = None
-    return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats)
+        for p, flag in zip(procs, saved_stats):
+            p.capture_stats = flag

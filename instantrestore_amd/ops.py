@@ -406,13 +406,36 @@ def linear_kernel_for(rows: int, n: int, k: int, bias: bool) -> int:
     return int(_lib.lib().ir_linear_kernel_for(int(rows), int(n), int(k), 1 if bias else 0))
 
 
+def linear_stats_rows(rows: int, n: int, k: int, bias: bool) -> int:
+    """rows per statistics block of ``linear(..., stats=...)`` for a shape (``ir_linear_stats_rows``); 0: the kernel that
+    serves the shape cannot leave statistics behind (``M`` not a multiple of its row block, ``N % 64 != 0``)"""
+    return int(_lib.lib().ir_linear_stats_rows(int(rows), int(n), int(k), 1 if bias else 0))
+
+
+class ColumnStats:
+    """partial token statistics of a column range of a projection output, as ``ir_linear_fwd_stats`` leaves them:
+    ``ws`` fp32 ``(M / rows, heads, 128)`` = mean[64] | M2[64] per (row block, head); ``rows`` tokens per block"""
+
+    __slots__ = ("ws", "rows", "heads")
+
+    def __init__(self, ws: torch.Tensor, rows: int, heads: int):
+        self.ws, self.rows, self.heads = ws, int(rows), int(heads)
+
+    def record_stream(self, stream) -> None:
+        self.ws.record_stream(stream)
+
+
 @_on_tensor_device
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, *, scale_cols: int = 0,
-           col_scale: float = 1.0, kernel: int = 0) -> torch.Tensor:
+           col_scale: float = 1.0, kernel: int = 0, stats: Optional[Tuple[int, int]] = None):
     """``F.linear(x, weight, bias)`` for ``x (..., K)``, 16-bit ``weight (N, K)`` (``ir_linear_fwd_ex``): fp32 accumulation,
     one rounding.  Raises for unsupported shapes.  ``scale_cols`` / ``col_scale``: the first ``scale_cols`` output columns
     are multiplied by ``col_scale`` in fp32 before that rounding.  ``x`` may be fp32: it is rounded to the weight's dtype
-    while loaded (the autocast cast, fused).  ``kernel``: ``LIN_KERNELS`` (0 = the library's own choice)."""
+    while loaded (the autocast cast, fused).  ``kernel``: ``LIN_KERNELS`` (0 = the library's own choice).
+
+    ``stats=(col0, cols)``: also return the partial token statistics of output columns ``[col0, col0 + cols)`` - whole
+    heads - computed by the GEMM's own workgroups from the block they have just stored (``ir_linear_fwd_stats``; the AdaIN
+    statistics without a pass over V): the result is ``(y, ColumnStats)``.  Check :func:`linear_stats_rows` first."""
     _need_gpu(x, weight, bias)
     _forward_only(x, weight, bias)
     n, k = weight.shape
@@ -420,11 +443,71 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     if x2.stride(1) != 1 or x2.stride(0) % 8 != 0:
         x2 = x2.contiguous()
     y = torch.empty((x2.shape[0], n), dtype=weight.dtype, device=x.device)
+    if stats is not None:
+        if kernel:
+            raise ValueError("stats: the kernel choice is the library's (kernel=0)")
+        col0, cols = int(stats[0]), int(stats[1])
+        rows = linear_stats_rows(x2.shape[0], n, k, bias is not None)
+        if rows <= 0 or cols <= 0 or cols % HEAD_DIM or col0 % HEAD_DIM:
+            raise ValueError(f"linear(stats=...): shape ({x2.shape[0]}, {n}, {k}) / columns ({col0}, {cols}) cannot carry the statistics tail")
+        ws = torch.empty((x2.shape[0] // rows, cols // HEAD_DIM, 128), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().ir_linear_fwd_stats(_dtype_code(weight), 1 if x.dtype == torch.float32 else 0, x2.shape[0], n, k, x2.data_ptr(),
+                                            x2.stride(0), weight.data_ptr(), weight.stride(0),
+                                            None if bias is None else bias.data_ptr(), y.data_ptr(), n, int(scale_cols),
+                                            float(col_scale), col0, cols, ws.data_ptr(), ws.numel() * 4, _stream())
+        _lib.check(rc, "ir_linear_fwd_stats")
+        return y.view(*x.shape[:-1], n), ColumnStats(ws, rows, cols // HEAD_DIM)
     rc = _lib.lib().ir_linear_fwd_ex(_dtype_code(weight), 1 if x.dtype == torch.float32 else 0, x2.shape[0], n, k, x2.data_ptr(), x2.stride(0), weight.data_ptr(),
                                      weight.stride(0), None if bias is None else bias.data_ptr(), y.data_ptr(), n,
                                      int(scale_cols), float(col_scale), int(kernel), _stream())
     _lib.check(rc, "ir_linear_fwd_ex")
     return y.view(*x.shape[:-1], n)
+
+
+@_on_tensor_device
+def adain_affine_from_partials(style: ColumnStats, batch: int, len_self: int, n_refs: int, len_ref: int, *,
+                               content: Optional[ColumnStats] = None, content_mean: Optional[torch.Tensor] = None,
+                               content_std: Optional[torch.Tensor] = None, valid: Optional[torch.Tensor] = None,
+                               eps: float = ADAIN_EPS):
+    """The AdaIN affine ``(a, b)`` of :func:`adain_stats` from the partials the projections left behind
+    (``ir_adain_affine_from_partials``): ``style`` from the shared layer's q/k/v GEMM over ``batch`` sets of ``len_self``
+    tokens; the content statistics either as the K/V-capture layer's partials (``content``, ``batch * n_refs`` sets of
+    ``len_ref`` tokens) or finished (``content_mean`` / ``content_std``, fp32 ``(B, N, H, 64)``).  ``valid``: int32 ``(B)``
+    on the device, references ``n >= valid[b]`` count as zero-filled."""
+    H = style.heads
+    dev = style.ws.device
+    if (content is None) == (content_mean is None or content_std is None):
+        raise ValueError("content statistics: either `content` partials or content_mean + content_std")
+    if content is not None and content.heads != H:
+        raise ValueError("style / content head counts differ")
+    for t in (content_mean, content_std):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or tuple(t.shape) != (batch, n_refs, H, HEAD_DIM)):
+            raise ValueError(f"content statistics must be contiguous fp32 ({batch}, {n_refs}, {H}, 64)")
+    if style.ws.shape[0] * style.rows != batch * len_self or (content is not None and content.ws.shape[0] * content.rows != batch * n_refs * len_ref):
+        raise ValueError("partials do not cover batch x len rows")
+    a = torch.empty((batch, n_refs, H, HEAD_DIM), dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    rc = _lib.lib().ir_adain_affine_from_partials(
+        batch, H, n_refs, len_self, len_ref, style.ws.data_ptr(), style.rows,
+        None if content is None else content.ws.data_ptr(), 0 if content is None else content.rows,
+        None if content_mean is None else content_mean.data_ptr(), None if content_std is None else content_std.data_ptr(),
+        None if valid is None else valid.data_ptr(), float(eps), a.data_ptr(), b.data_ptr(), _stream())
+    _lib.check(rc, "ir_adain_affine_from_partials")
+    return a, b
+
+
+@_on_tensor_device
+def token_stats_from_partials(part: ColumnStats, n_sets: int, length: int):
+    """mean and unbiased std over the tokens of ``n_sets`` matrices of ``length`` rows from their partials
+    (``ir_token_stats_from_partials``): two fp32 ``(n_sets, H, 64)`` tensors, what :func:`token_stats` returns per matrix"""
+    if part.ws.shape[0] * part.rows != n_sets * length:
+        raise ValueError("partials do not cover n_sets x length rows")
+    mean = torch.empty((n_sets, part.heads, HEAD_DIM), dtype=torch.float32, device=part.ws.device)
+    std = torch.empty_like(mean)
+    rc = _lib.lib().ir_token_stats_from_partials(n_sets, part.heads, length, part.ws.data_ptr(), part.rows, mean.data_ptr(),
+                                                 std.data_ptr(), _stream())
+    _lib.check(rc, "ir_token_stats_from_partials")
+    return mean, std
 
 
 _ANY_DT = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}

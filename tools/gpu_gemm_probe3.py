@@ -34,6 +34,12 @@ for (L, C) in ((256, 1280), (1024, 640), (4096, 320)):
         shapes += [(sets * L, 3 * C, C, False), (sets * L, C, C, True)]
 if len(sys.argv) > 1 and sys.argv[1] == "big":
     shapes = [(128 * 1024, 3840, 1280, False), (128 * 1024, 1280, 1280, True), (16 * 1024, 3840, 1280, False)]
+if len(sys.argv) > 1 and sys.argv[1] == "small":
+    # the tiny-M regime the round-3 probes never measured - cross-attention to_k / to_v over the text states
+    # (M = 77 B, K = 1024), the mid block's projections (8 x 8 tokens: M = 64 B), one identity (M = L)
+    shapes = [(M, N, K, b) for K in (1024, 1280) for M in (77, 616, 1024) for (N, b) in ((1280, False), (3840, False), (1280, True))
+              if not (K == 1024 and N == 3840)]
+    shapes += [(512, 3840, 1280, False), (512, 1280, 1280, True), (256, 960, 320, False), (4096, 960, 320, False), (64, 3840, 1280, False)]
 dt = torch.bfloat16
 g = torch.Generator().manual_seed(1)
 tot_v = tot_o = 0.0

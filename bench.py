@@ -143,7 +143,11 @@ def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached
         p = ly["kv_attn"].processor
         keys.append(p.keys.reshape(-1, N, p.keys.shape[1], p.keys.shape[2]))
         vals.append(p.values.reshape(-1, N, p.values.shape[1], p.values.shape[2]))
-        stats.append(None if p.v_mean is None else (p.v_mean.reshape(-1, N, *p.v_mean.shape[-2:]), p.v_std.reshape(-1, N, *p.v_std.shape[-2:])))
+        if p.v_part is not None:    # round 4: content statistics as the capture GEMM's partials, merged by the shared layer's affine kernel
+            from instantrestore_amd import ops as _o
+            stats.append(_o.RefStatsPartials(p.v_part, p.values.shape[0] // N, N, p.values.shape[1]))
+        else:
+            stats.append(None if p.v_mean is None else (p.v_mean.reshape(-1, N, *p.v_mean.shape[-2:]), p.v_std.reshape(-1, N, *p.v_std.shape[-2:])))
         events.append(p.ready)
         p.reset()
     # 3. shared attention on the degraded images (each layer waits for its own reference layer's event)
@@ -923,7 +927,10 @@ def main():
                     p = ly["kv_attn"].processor
                     keys.append(p.keys.reshape(-1, N, *p.keys.shape[1:]).clone())
                     vals.append(p.values.reshape(-1, N, *p.values.shape[1:]).clone())
-                    cst.append(None if p.v_mean is None else (p.v_mean.reshape(-1, N, *p.v_mean.shape[-2:]).clone(), p.v_std.reshape(-1, N, *p.v_std.shape[-2:]).clone()))
+                    if p.v_part is not None:
+                        cst.append(_ops_mod.RefStatsPartials(p.v_part, p.values.shape[0] // N, N, p.values.shape[1]).finished())
+                    else:
+                        cst.append(None if p.v_mean is None else (p.v_mean.reshape(-1, N, *p.v_mean.shape[-2:]).clone(), p.v_std.reshape(-1, N, *p.v_std.shape[-2:]).clone()))
                     p.reset()
                 secc = _time_steps(lambda: hot_path_step(layers, B, N, cached_kv=(keys, vals, cst if use_adain else None)), args.steps)
                 extras["kv_cached"] = {"images_per_s": round(B / secc, 2), "ms_per_step": round(secc * 1e3, 4),

@@ -55,7 +55,7 @@ def main(argv=None):
     from face_replace.models.attn_processors import register_attention_processor, register_attention_processor_kv_unet
     from instantrestore_amd import ops
     from instantrestore_amd.kv_cache import ReferenceKVCache
-    from instantrestore_amd.kv_harvest import enable_ref_stats, enable_stream_overlap, harvest_reference_kv
+    from instantrestore_amd.kv_harvest import enable_ref_stats, enable_stream_overlap, finished_stats, harvest_reference_kv
     from instantrestore_amd.attn_processors import ReferenceCaptureComplete, AttnProcessor
     from instantrestore_amd.preprocess import LanczosPreprocessor
     from instantrestore_amd.unet_host import AttnTopologyUNet
@@ -111,6 +111,7 @@ def main(argv=None):
         # NEXT FRAME of the same identities: the references have not changed, so neither have their K/V nor their AdaIN
         # content statistics - both come out of the per-identity cache and the whole reference branch is skipped
         cache = ReferenceKVCache(max_identities=max(8, B))
+        stats = finished_stats(stats)                         # (mean, std) pairs: sliceable per identity
         for b in range(B):
             cache.get_or_compute("id%d" % b, lambda b=b: ([k[b:b + 1] for k in keys], [v[b:b + 1] for v in values],
                                                           [(m[b:b + 1], sd[b:b + 1]) for m, sd in stats]))

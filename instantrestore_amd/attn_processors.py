@@ -170,7 +170,7 @@ def _project_qkv(attn, st: _Prepared, want_stats: bool = False):
     if want_stats and FUSED_STATS and own and x.dim() == 3 and c % _ops.HEAD_DIM == 0:
         # token statistics of the V third as the GEMM's tail: whole row blocks per token set (rows | L), whole heads
         rows = _ops.linear_stats_rows(x.shape[0] * x.shape[1], 3 * c, w.shape[1], False)
-        if rows > 0 and x.shape[1] % rows == 0:
+        if rows > 0 and x.shape[1] % rows == 0 and x.shape[1] // rows <= _ops.STATS_MAX_CHUNKS:
             qkv, vstats = _ops.linear(x, w, None, stats=(2 * c, c), **kw)
     if vstats is None:
         qkv = _ops.linear(x, w, None, **kw) if presc else _linear(x, w, None)
@@ -255,6 +255,8 @@ class AttnProcessor(nn.Module):
         self.stream = None                # HIP stream the K/V were produced on (kv_harvest orders its zero fill after it)
         self.capture_stats = False        # True (kv_harvest.enable_ref_stats): also stash the AdaIN CONTENT statistics of
         self.v_mean, self.v_std = None, None   # every reference V, fp32 (B*N, H, 64) - constant per identity
+        self.v_part = None                # ... or (round 4) the partials the q/k/v GEMM left behind (ops.ColumnStats): merged
+                                          # by the shared layer's affine kernel, or into (mean, std) on demand
 
     def reset(self):
         self.keys, self.values = None, None
@@ -262,17 +264,17 @@ class AttnProcessor(nn.Module):
         self.ready = None
         self.stream = None
         self.v_mean, self.v_std = None, None
+        self.v_part = None
 
     def _stash_stats(self, attn, vstats=None):
         """mean and unbiased std over the tokens of every captured V, per (head, channel): the content statistics of
         ``adain`` (attn_processors.py:9-10) computed HERE, once per reference and on the capture stream, instead of in
         every shared layer of every frame.  ``vstats``: the partials the q/k/v GEMM left behind (round 4: no pass over V,
         one 64-thread-per-(set, head) merge); without them ``ir_token_stats`` reads V."""
-        if not self.capture_stats:
-            self.v_mean, self.v_std = None, None     # never hand a later harvest the statistics of an earlier capture
-        elif self.values.is_cuda:
+        self.v_mean, self.v_std, self.v_part = None, None, None     # never hand a later harvest the statistics of an earlier capture
+        if self.capture_stats and self.values.is_cuda:
             if vstats is not None:
-                self.v_mean, self.v_std = _ops.token_stats_from_partials(vstats, self.values.shape[0], self.values.shape[1])
+                self.v_part = vstats       # merged where they are consumed (kv_harvest / SharedAttnProcessor): no launch here
             else:
                 m, sd = _ops.token_stats(self.values.unsqueeze(1), heads=attn.heads)      # (B*N, 1, H, 64) each
                 self.v_mean, self.v_std = m[:, 0], sd[:, 0]
@@ -378,7 +380,9 @@ class SharedAttnProcessor(nn.Module):
                 cur.wait_event(ref_events[self.self_attn_idx])
                 ref_k.record_stream(cur)
                 ref_v.record_stream(cur)
-                if cstats is not None:
+                if hasattr(cstats, "finished"):
+                    cstats.record_stream(cur)
+                elif cstats is not None:
                     cstats[0].record_stream(cur)
                     cstats[1].record_stream(cur)
             include_self = bool(self.train_input)
@@ -388,7 +392,13 @@ class SharedAttnProcessor(nn.Module):
                 # only V_self is read here - 1/(N+1) of the bytes, the same (a, b) bit for bit
                 # Round 4: the style statistics arrive as the partials this layer's own q/k/v GEMM left behind (``vstats``):
                 # with them and the content statistics nothing of V is read here at all - one small launch
-                if cstats is not None and vstats is not None:
+                if hasattr(cstats, "finished"):
+                    if vstats is not None:    # both sides as partials: ONE launch merges them into the affine
+                        affine = _ops.adain_affine_from_partials(vstats, value.shape[0], value.shape[1], ref_v.shape[1], ref_v.shape[2],
+                                                                 content=cstats.part, valid=cstats.valid)
+                    else:
+                        affine = _stats_cached(value, cstats.finished(), attn.heads)
+                elif cstats is not None and vstats is not None:
                     affine = _ops.adain_affine_from_partials(vstats, value.shape[0], value.shape[1], ref_v.shape[1], ref_v.shape[2],
                                                              content_mean=cstats[0], content_std=cstats[1])
                 elif cstats is not None:

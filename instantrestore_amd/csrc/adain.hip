@@ -477,78 +477,115 @@ hipError_t ir_launch_tensor2im(const void* x, void* out, int dtype, int64_t sb, 
 // token order, so a matrix's partials are consecutive: ws[(set * len / rows + c) * H + h][128].  No pass over V is left.
 namespace {
 
-// merged (mean, M2) of one matrix's `nch` equal-sized partials for channel d; loads batched eight chunks ahead of the
-// serial Chan merges (the merge order is the chunk order: deterministic)
-__device__ __forceinline__ void merge_partials(const float* w, int64_t stride, int nch, float rows, int d, float& mean, float& m2) {
-  float cn = 0.f;
-  mean = 0.f; m2 = 0.f;
-  int c = 0;
-  for (; c + 8 <= nch; c += 8) {
-    float mu[8], mm[8];
+// (mean, M2) of a matrix from its `nch` partials of `rows` tokens each, by the 1024 threads of a workgroup: thread (g, d),
+// g = tid >> 6 in [0, 16), holds chunks g, g + 16, ... of channel d in registers (all loads in flight at once: the kernel
+// is one memory latency long).  Equal counts make the merge a two-pass sum with no serial chain:
+//   mean = (1 / nch) * sum_i mean_i,     M2 = sum_i [ M2_i + rows * (mean_i - mean)^2 ]
+// (first version: Chan partials merged one after another by one thread per channel - 64 dependent divisions at the
+// 64 x 64-token class, 9.7 us per launch; second: 256 threads re-reading memory in both passes, 16 us).  The sums over g
+// run in a fixed order: deterministic.
+constexpr int kMergePer = 16;      // chunks per thread held in registers: nch <= 256 (16 384 tokens in 64-row blocks)
+
+struct MergeRegs {
+  float m[kMergePer], q[kMergePer];
+};
+
+__device__ __forceinline__ void merge_load(MergeRegs& r, const float* __restrict__ w, int64_t stride, int nch, int g, int d) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { mu[i] = w[(c + i) * stride + d]; mm[i] = w[(c + i) * stride + 64 + d]; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) chan_merge(cn, mean, m2, rows, mu[i], mm[i]);
+  for (int i = 0; i < kMergePer; ++i) {
+    const int c = g + 16 * i;
+    r.m[i] = c < nch ? w[c * stride + d] : 0.f;
+    r.q[i] = c < nch ? w[c * stride + 64 + d] : 0.f;
   }
-  for (; c < nch; ++c) chan_merge(cn, mean, m2, rows, w[c * stride + d], w[c * stride + 64 + d]);
+}
+__device__ __forceinline__ float merge_sum_mean(const MergeRegs& r) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMergePer; ++i) s += r.m[i];
+  return s;
+}
+__device__ __forceinline__ float merge_sum_m2(const MergeRegs& r, int nch, int g, float rows, float mean) {
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < kMergePer; ++i) {
+    const float dm = r.m[i] - mean;
+    if (g + 16 * i < nch) q += r.q[i] + rows * dm * dm;
+  }
+  return q;
+}
+__device__ __forceinline__ float sum16(const float* red, int d) {   // over the 16 groups, fixed order
+  float s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; ++g) s += red[g * 64 + d];
+  return s;
 }
 
-// grid: (B*H); 256 threads = 4 matrices at a time x 64 channels.  LDS: (1 + N) x 128 floats.
-__global__ void __launch_bounds__(256) adain_affine_partials_kernel(const AdainPartialsKParams p) {
-  extern __shared__ __attribute__((aligned(16))) float psm[];
+// grid: (B*N*H); 1024 threads.  One workgroup per (b, n, h): style (V_self of b) + content (reference n) -> a, b.
+__global__ void __launch_bounds__(1024) adain_affine_partials_kernel(const AdainPartialsKParams p) {
+  __shared__ float red[4][1024];
   const int tid = threadIdx.x, d = tid & 63, g = tid >> 6;
-  const int h = blockIdx.x % p.H, b = blockIdx.x / p.H;
+  int idx = blockIdx.x;
+  const int h = idx % p.H; idx /= p.H;
+  const int n = idx % p.N, b = idx / p.N;
   const int64_t hs = (int64_t)p.H * 128;
-  const int nmat = p.content_ws != nullptr ? 1 + p.N : 1;
-  for (int j = g; j < nmat; j += 4) {
-    float mean, m2;
-    if (j == 0) {
-      const int nch = p.Ls / p.style_rows;
-      merge_partials(p.style_ws + ((int64_t)b * nch) * hs + h * 128, hs, nch, (float)p.style_rows, d, mean, m2);
-    } else {
-      const int nch = p.Lr / p.content_rows;
-      merge_partials(p.content_ws + ((int64_t)(b * p.N + j - 1) * nch) * hs + h * 128, hs, nch, (float)p.content_rows, d, mean, m2);
-    }
-    psm[j * 128 + d] = mean;
-    psm[j * 128 + 64 + d] = m2;
-  }
+  const int nch_s = p.Ls / p.style_rows;
+  const bool zeroed = p.valid != nullptr && n >= p.valid[b];       // zero-filled reference (pix2pix_turbo.py:269-273): statistics (0, 0)
+  const bool merge_c = p.content_ws != nullptr && !zeroed;
+  const int nch_c = merge_c ? p.Lr / p.content_rows : 0;
+  MergeRegs rs, rc;
+  merge_load(rs, p.style_ws + ((int64_t)b * nch_s) * hs + h * 128, hs, nch_s, g, d);
+  merge_load(rc, merge_c ? p.content_ws + ((int64_t)(b * p.N + n) * nch_c) * hs + h * 128 : p.style_ws, hs, nch_c, g, d);
+  red[0][tid] = merge_sum_mean(rs);
+  red[1][tid] = merge_sum_mean(rc);
   __syncthreads();
-  const int nvalid = p.valid != nullptr ? p.valid[b] : p.N;
-  for (int i = tid; i < p.N * 64; i += 256) {
-    const int n = i >> 6, dd = i & 63;
-    const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + dd;
+  const float mean_s = sum16(red[0], d) / (float)nch_s;
+  const float mean_c = merge_c ? sum16(red[1], d) / (float)nch_c : 0.f;
+  red[2][tid] = merge_sum_m2(rs, nch_s, g, (float)p.style_rows, mean_s);
+  red[3][tid] = merge_sum_m2(rc, nch_c, g, (float)p.content_rows, mean_c);
+  __syncthreads();
+  if (g == 0) {
+    const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
     float mu_x, sd_x;
-    if (n >= nvalid) { mu_x = 0.f; sd_x = 0.f; }     // zero-filled reference (pix2pix_turbo.py:269-273): statistics (0, 0)
-    else if (p.content_ws != nullptr) { mu_x = psm[(1 + n) * 128 + dd]; sd_x = sqrtf(psm[(1 + n) * 128 + 64 + dd] / (float)(p.Lr - 1)); }
+    if (zeroed) { mu_x = 0.f; sd_x = 0.f; }
+    else if (merge_c) { mu_x = mean_c; sd_x = sqrtf(sum16(red[3], d) / (float)(p.Lr - 1)); }
     else { mu_x = p.cmean[o]; sd_x = p.cstd[o]; }
-    const float sd_v = sqrtf(psm[64 + dd] / (float)(p.Ls - 1)) + p.eps;
+    const float sd_v = sqrtf(sum16(red[2], d) / (float)(p.Ls - 1)) + p.eps;
     const float a = sd_v / (sd_x + p.eps);
     p.a[o] = a;
-    p.b[o] = psm[dd] - mu_x * a;
+    p.b[o] = mean_s - mu_x * a;
   }
 }
 
-// grid: (nsets*H); 64 threads.  mean / unbiased std of every matrix from its partials.
-__global__ void __launch_bounds__(64) token_stats_partials_kernel(const float* ws, int rows, int H, int len, float* mean_out, float* std_out) {
-  const int d = threadIdx.x;
+// grid: (nsets*H); 1024 threads.  mean / unbiased std of every matrix from its partials.
+__global__ void __launch_bounds__(1024) token_stats_partials_kernel(const float* ws, int rows, int H, int len, float* mean_out, float* std_out) {
+  __shared__ float red[2][1024];
+  const int tid = threadIdx.x, d = tid & 63, g = tid >> 6;
   const int h = blockIdx.x % H, set = blockIdx.x / H;
   const int nch = len / rows;
-  float mean, m2;
-  merge_partials(ws + ((int64_t)set * nch) * H * 128 + h * 128, (int64_t)H * 128, nch, (float)rows, d, mean, m2);
-  const int64_t o = ((int64_t)set * H + h) * 64 + d;
-  mean_out[o] = mean;
-  std_out[o] = sqrtf(m2 / (float)(len - 1));
+  MergeRegs r;
+  merge_load(r, ws + ((int64_t)set * nch) * H * 128 + h * 128, (int64_t)H * 128, nch, g, d);
+  red[0][tid] = merge_sum_mean(r);
+  __syncthreads();
+  const float mean = sum16(red[0], d) / (float)nch;
+  red[1][tid] = merge_sum_m2(r, nch, g, (float)rows, mean);
+  __syncthreads();
+  if (g == 0) {
+    const int64_t o = ((int64_t)set * H + h) * 64 + d;
+    mean_out[o] = mean;
+    std_out[o] = sqrtf(sum16(red[1], d) / (float)(len - 1));
+  }
 }
 
 }  // namespace
 
 hipError_t ir_launch_adain_affine_partials(const AdainPartialsKParams& p, hipStream_t s) {
-  const size_t lds = (size_t)(1 + p.N) * 128 * sizeof(float);
-  hipLaunchKernelGGL(adain_affine_partials_kernel, dim3(p.B * p.H), dim3(256), lds, s, p);
+  hipLaunchKernelGGL(adain_affine_partials_kernel, dim3(p.B * p.N * p.H), dim3(1024), 0, s, p);
   return hipGetLastError();
 }
 
 hipError_t ir_launch_token_stats_partials(const float* ws, int rows, int nsets, int H, int len, float* mean, float* std, hipStream_t s) {
-  hipLaunchKernelGGL(token_stats_partials_kernel, dim3(nsets * H), dim3(64), 0, s, ws, rows, H, len, mean, std);
+  hipLaunchKernelGGL(token_stats_partials_kernel, dim3(nsets * H), dim3(1024), 0, s, ws, rows, H, len, mean, std);
   return hipGetLastError();
 }
+
+int ir_adain_partials_max_chunks(void) { return 16 * kMergePer; }

@@ -455,7 +455,8 @@ int ir_adain_affine_from_partials(int32_t batch, int32_t heads, int32_t n_refs, 
   } else if (!content_mean || !content_std) {
     return fail(IR_ERR_INVALID_ARG, "content statistics: either content_ws or content_mean + content_std");
   }
-  if ((size_t)(1 + n_refs) * 128 * sizeof(float) > 60 * 1024) return fail(IR_ERR_UNSUPPORTED, "n_refs %d: too many references", n_refs);
+  if (len_self / style_rows > ir_adain_partials_max_chunks() || (content_ws != nullptr && len_ref / content_rows > ir_adain_partials_max_chunks()))
+    return fail(IR_ERR_UNSUPPORTED, "more than %d partials per matrix (token axis too long for the merge kernel: use ir_adain_stats)", ir_adain_partials_max_chunks());
   AdainPartialsKParams p;
   memset(&p, 0, sizeof(p));
   p.style_ws = style_ws; p.content_ws = content_ws; p.cmean = content_mean; p.cstd = content_std; p.valid = valid;
@@ -471,6 +472,7 @@ int ir_token_stats_from_partials(int32_t n_sets, int32_t heads, int32_t len, con
   if (n_sets <= 0 || heads <= 0 || len <= 0) return fail(IR_ERR_INVALID_ARG, "sizes must be > 0");
   if (!ws || !mean || !std) return fail(IR_ERR_INVALID_ARG, "NULL pointer");
   if (rows <= 0 || (len % rows) != 0) return fail(IR_ERR_INVALID_ARG, "len %d is not a multiple of rows %d", len, rows);
+  if (len / rows > ir_adain_partials_max_chunks()) return fail(IR_ERR_UNSUPPORTED, "more than %d partials per matrix", ir_adain_partials_max_chunks());
   const hipError_t e = ir_launch_token_stats_partials(ws, rows, n_sets, heads, len, mean, std, (hipStream_t)stream);
   if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "token_stats_partials launch: %s", hipGetErrorString(e));
   return IR_OK;

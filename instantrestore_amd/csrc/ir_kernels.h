@@ -132,6 +132,7 @@ struct AdainPartialsKParams {
 };
 hipError_t ir_launch_adain_affine_partials(const AdainPartialsKParams& p, hipStream_t s);
 hipError_t ir_launch_token_stats_partials(const float* ws, int rows, int nsets, int H, int len, float* mean, float* std, hipStream_t s);
+int ir_adain_partials_max_chunks(void);   // partials per matrix the merge kernels hold in registers (len / rows <= this)
 hipError_t ir_launch_adain_apply(const AdainApplyKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_zero_refs(const ZeroRefsKParams& p, hipStream_t s);
 hipError_t ir_launch_tensor2im(const void* x, void* out, int dtype, int64_t sb, int64_t sc, int64_t sh, int64_t sw,

@@ -52,6 +52,8 @@ class ReferenceKVCache:
             raise ValueError("compute() must return (keys, values) or (keys, values, stats); harvest with with_events=False")
         keys, values = res[0], res[1]
         stats = res[2] if len(res) > 2 else None
+        if stats is not None:      # statistics still in the GEMM-partials form (ops.RefStatsPartials): a cache entry holds them finished
+            stats = [st.finished() if hasattr(st, "finished") else st for st in stats]
         if len(keys) != len(values) or any(k.shape[0] != 1 or k.shape != v.shape for k, v in zip(keys, values)):
             raise ValueError("compute() must return matching lists of (1, N, L, C) tensors")
         if stats is not None:

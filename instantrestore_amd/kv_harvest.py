@@ -28,8 +28,9 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
     ``cross_attention_kwargs={'ref_keys': ..., 'ref_values': ..., 'ref_events': ...}`` when the two UNets
     run on different streams.
 
-    ``with_stats`` appends ``stats``: per layer ``(mean, std)`` of every reference V over its tokens, fp32
-    ``(B, N, H, 64)`` - the CONTENT statistics of AdaIN (attn_processors.py:9-10), stashed by the capturing processors
+    ``with_stats`` appends ``stats``: per layer either ``ops.RefStatsPartials`` (round 4: the statistics as the capture
+    layer's q/k/v GEMM left them; ``.finished()`` gives the pair below) or ``(mean, std)`` of every reference V over its tokens,
+    fp32 ``(B, N, H, 64)`` - the CONTENT statistics of AdaIN (attn_processors.py:9-10), stashed by the capturing processors
     (:func:`enable_ref_stats`) or computed here when they were not; pass it on as ``'ref_stats'`` and the shared layers
     read only their own V (``ir_adain_stats_cached``).  References zero-filled below get the statistics of an all-zero
     V, (0, 0): exactly what the uncached path computes from the zeroed tensor (the ``b == mean(V_self)`` quirk)."""
@@ -46,7 +47,11 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
         v = p.values.reshape(-1, n_refs, p.values.shape[1], p.values.shape[2])
         keys.append(k)
         values.append(v)
-        if with_stats:
+        if with_stats and getattr(p, "v_part", None) is not None:
+            # round 4: the capture layer's q/k/v GEMM left the partial statistics of its V third behind; they travel as they
+            # are (the shared layer's affine kernel merges them), with the valid counts when references get zero-filled below
+            stats.append(_ops.RefStatsPartials(p.v_part, v.shape[0], n_refs, v.shape[2]))
+        elif with_stats:
             m, sd = getattr(p, "v_mean", None), getattr(p, "v_std", None)
             if m is None and v.is_cuda:      # not stashed at capture time: one pass over V now, behind its producer
                 cur = torch.cuda.current_stream(v.device)
@@ -75,8 +80,11 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
         if with_stats and keys[0].is_cuda:
             # the zero fill invalidates the cached statistics of the zeroed references: an all-zero V has mean 0, std 0
             keep = (torch.arange(n_refs)[None, :] < valid.reshape(-1, 1)).to(device=keys[0].device, dtype=torch.float32)[:, :, None, None]
+            valid_dev = valid.to(device=keys[0].device, dtype=torch.int32).contiguous()
             for st in stats:
-                if st is not None:
+                if hasattr(st, "finished"):
+                    st.valid = valid_dev          # the affine kernel (and finished()) count these references as all-zero
+                elif st is not None:
                     for t in st:
                         t.record_stream(torch.cuda.current_stream(t.device))
                         t.mul_(keep)
@@ -91,6 +99,13 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
             events = [ev] * len(keys)
         return (keys, values, events, stats) if with_stats else (keys, values, events)
     return (keys, values, stats) if with_stats else (keys, values)
+
+
+def finished_stats(stats):
+    """the harvested AdaIN content statistics as per-layer ``(mean, std)`` pairs of fp32 ``(B, N, H, 64)`` tensors - what a
+    per-identity cache stores and slices - whichever form the harvest handed them over in (``ops.RefStatsPartials`` when the
+    capture GEMM produced them, pairs already otherwise)"""
+    return [st.finished() if hasattr(st, "finished") else st for st in stats]
 
 
 def enable_ref_stats(original_unet, enabled: bool = True) -> None:

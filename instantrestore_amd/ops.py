@@ -406,6 +406,9 @@ def linear_kernel_for(rows: int, n: int, k: int, bias: bool) -> int:
     return int(_lib.lib().ir_linear_kernel_for(int(rows), int(n), int(k), 1 if bias else 0))
 
 
+STATS_MAX_CHUNKS = 256   # partials per matrix the merge kernels take (ir_adain_affine_from_partials): 16 384 tokens in 64-row blocks
+
+
 def linear_stats_rows(rows: int, n: int, k: int, bias: bool) -> int:
     """rows per statistics block of ``linear(..., stats=...)`` for a shape (``ir_linear_stats_rows``); 0: the kernel that
     serves the shape cannot leave statistics behind (``M`` not a multiple of its row block, ``N % 64 != 0``)"""
@@ -423,6 +426,32 @@ class ColumnStats:
 
     def record_stream(self, stream) -> None:
         self.ws.record_stream(stream)
+
+
+class RefStatsPartials:
+    """AdaIN CONTENT statistics of the reference V's of one layer, still in the form the K/V-capture layer's q/k/v GEMM left
+    them in: ``part`` = partials over ``batch * n_refs`` token sets of ``length`` rows.  The shared layer's affine kernel
+    merges them directly (one launch per layer instead of a merge on the capture side plus the affine); ``finished()`` gives
+    the ``(mean, std)`` pair of ``(B, N, H, 64)`` tensors that a per-identity cache stores.  ``valid``: int32 ``(B,)`` device
+    tensor when references ``n >= valid[b]`` were zero-filled by the harvest (statistics (0, 0)), else ``None``."""
+
+    __slots__ = ("part", "batch", "n_refs", "length", "valid")
+
+    def __init__(self, part: ColumnStats, batch: int, n_refs: int, length: int, valid: Optional[torch.Tensor] = None):
+        self.part, self.batch, self.n_refs, self.length, self.valid = part, int(batch), int(n_refs), int(length), valid
+
+    def record_stream(self, stream) -> None:
+        self.part.ws.record_stream(stream)
+        if self.valid is not None:
+            self.valid.record_stream(stream)
+
+    def finished(self):
+        mean, std = token_stats_from_partials(self.part, self.batch * self.n_refs, self.length)
+        mean, std = mean.reshape(self.batch, self.n_refs, *mean.shape[-2:]), std.reshape(self.batch, self.n_refs, *std.shape[-2:])
+        if self.valid is not None:
+            keep = (torch.arange(self.n_refs, device=mean.device)[None, :] < self.valid.reshape(-1, 1)).to(torch.float32)[:, :, None, None]
+            mean, std = mean * keep, std * keep
+        return mean.contiguous(), std.contiguous()
 
 
 @_on_tensor_device

@@ -10,6 +10,7 @@ import torch
 from oracle import shared_attn_oracle as O
 
 HEAD_DIM = 64
+STATS_MAX_CHUNKS = 256
 ADAIN_EPS = 1e-5
 CALLS = []  # (name, info) log so tests can assert which entry points the processors used
 

@@ -57,6 +57,10 @@ def test_zero_filled_reference_keeps_the_style_mean_quirk_through_the_cache(fuse
     assert len(stats) == 9
     for l, (v, st) in enumerate(zip(vals, stats)):
         B, N, L, C = v.shape
+        # GEMM partials travel as they are (.finished() = the (mean, std) pair) wherever the token axis is whole 64-row blocks;
+        # the 4 x 4-token layers of this 16 x 16 latent keep the standalone pass
+        assert hasattr(st, "finished") == bool(fused and L % 64 == 0)
+        st = st.finished() if hasattr(st, "finished") else st
         H = C // 64
         assert st[0].shape == (B, N, H, 64) and float(st[0][1, 1].abs().max()) == 0.0 and float(st[1][1, 1].abs().max()) == 0.0
         vs = torch.randn(B, L, C, device="cuda").to(v.dtype)

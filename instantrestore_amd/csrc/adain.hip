@@ -484,32 +484,38 @@ namespace {
 // (first version: Chan partials merged one after another by one thread per channel - 64 dependent divisions at the
 // 64 x 64-token class, 9.7 us per launch; second: 256 threads re-reading memory in both passes, 16 us).  The sums over g
 // run in a fixed order: deterministic.
-constexpr int kMergePer = 16;      // chunks per thread held in registers: nch <= 256 (16 384 tokens in 64-row blocks)
+constexpr int kMergePerMax = 16;   // chunks per thread held in registers: nch <= 256 (16 384 tokens in 64-row blocks)
 
+template <int PER>
 struct MergeRegs {
-  float m[kMergePer], q[kMergePer];
+  float m[PER], q[PER];
 };
 
-__device__ __forceinline__ void merge_load(MergeRegs& r, const float* __restrict__ w, int64_t stride, int nch, int g, int d) {
+// every load unconditional (out-of-range chunks re-read the last one and are weighted out): all 2 PER loads in flight at once
+template <int PER>
+__device__ __forceinline__ void merge_load(MergeRegs<PER>& r, const float* __restrict__ w, int64_t stride, int nch, int g, int d) {
 #pragma unroll
-  for (int i = 0; i < kMergePer; ++i) {
+  for (int i = 0; i < PER; ++i) {
     const int c = g + 16 * i;
-    r.m[i] = c < nch ? w[c * stride + d] : 0.f;
-    r.q[i] = c < nch ? w[c * stride + 64 + d] : 0.f;
+    const int cc = c < nch ? c : (nch > 0 ? nch - 1 : 0);
+    r.m[i] = w[cc * stride + d];
+    r.q[i] = w[cc * stride + 64 + d];
   }
 }
-__device__ __forceinline__ float merge_sum_mean(const MergeRegs& r) {
+template <int PER>
+__device__ __forceinline__ float merge_sum_mean(const MergeRegs<PER>& r, int nch, int g) {
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < kMergePer; ++i) s += r.m[i];
+  for (int i = 0; i < PER; ++i) s += (g + 16 * i < nch) ? r.m[i] : 0.f;
   return s;
 }
-__device__ __forceinline__ float merge_sum_m2(const MergeRegs& r, int nch, int g, float rows, float mean) {
+template <int PER>
+__device__ __forceinline__ float merge_sum_m2(const MergeRegs<PER>& r, int nch, int g, float rows, float mean) {
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < kMergePer; ++i) {
+  for (int i = 0; i < PER; ++i) {
     const float dm = r.m[i] - mean;
-    if (g + 16 * i < nch) q += r.q[i] + rows * dm * dm;
+    q += (g + 16 * i < nch) ? (r.q[i] + rows * dm * dm) : 0.f;
   }
   return q;
 }
@@ -521,6 +527,7 @@ __device__ __forceinline__ float sum16(const float* red, int d) {   // over the 
 }
 
 // grid: (B*N*H); 1024 threads.  One workgroup per (b, n, h): style (V_self of b) + content (reference n) -> a, b.
+template <int PER>
 __global__ void __launch_bounds__(1024) adain_affine_partials_kernel(const AdainPartialsKParams p) {
   __shared__ float red[4][1024];
   const int tid = threadIdx.x, d = tid & 63, g = tid >> 6;
@@ -532,16 +539,17 @@ __global__ void __launch_bounds__(1024) adain_affine_partials_kernel(const Adain
   const bool zeroed = p.valid != nullptr && n >= p.valid[b];       // zero-filled reference (pix2pix_turbo.py:269-273): statistics (0, 0)
   const bool merge_c = p.content_ws != nullptr && !zeroed;
   const int nch_c = merge_c ? p.Lr / p.content_rows : 0;
-  MergeRegs rs, rc;
-  merge_load(rs, p.style_ws + ((int64_t)b * nch_s) * hs + h * 128, hs, nch_s, g, d);
-  merge_load(rc, merge_c ? p.content_ws + ((int64_t)(b * p.N + n) * nch_c) * hs + h * 128 : p.style_ws, hs, nch_c, g, d);
-  red[0][tid] = merge_sum_mean(rs);
-  red[1][tid] = merge_sum_mean(rc);
+  MergeRegs<PER> rs, rc;
+  merge_load<PER>(rs, p.style_ws + ((int64_t)b * nch_s) * hs + h * 128, hs, nch_s, g, d);
+  merge_load<PER>(rc, merge_c ? p.content_ws + ((int64_t)(b * p.N + n) * nch_c) * hs + h * 128 : p.style_ws + ((int64_t)b * nch_s) * hs + h * 128,
+                  hs, merge_c ? nch_c : 1, g, d);
+  red[0][tid] = merge_sum_mean<PER>(rs, nch_s, g);
+  red[1][tid] = merge_sum_mean<PER>(rc, nch_c, g);
   __syncthreads();
   const float mean_s = sum16(red[0], d) / (float)nch_s;
   const float mean_c = merge_c ? sum16(red[1], d) / (float)nch_c : 0.f;
-  red[2][tid] = merge_sum_m2(rs, nch_s, g, (float)p.style_rows, mean_s);
-  red[3][tid] = merge_sum_m2(rc, nch_c, g, (float)p.content_rows, mean_c);
+  red[2][tid] = merge_sum_m2<PER>(rs, nch_s, g, (float)p.style_rows, mean_s);
+  red[3][tid] = merge_sum_m2<PER>(rc, nch_c, g, (float)p.content_rows, mean_c);
   __syncthreads();
   if (g == 0) {
     const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
@@ -557,17 +565,18 @@ __global__ void __launch_bounds__(1024) adain_affine_partials_kernel(const Adain
 }
 
 // grid: (nsets*H); 1024 threads.  mean / unbiased std of every matrix from its partials.
+template <int PER>
 __global__ void __launch_bounds__(1024) token_stats_partials_kernel(const float* ws, int rows, int H, int len, float* mean_out, float* std_out) {
   __shared__ float red[2][1024];
   const int tid = threadIdx.x, d = tid & 63, g = tid >> 6;
   const int h = blockIdx.x % H, set = blockIdx.x / H;
   const int nch = len / rows;
-  MergeRegs r;
-  merge_load(r, ws + ((int64_t)set * nch) * H * 128 + h * 128, (int64_t)H * 128, nch, g, d);
-  red[0][tid] = merge_sum_mean(r);
+  MergeRegs<PER> r;
+  merge_load<PER>(r, ws + ((int64_t)set * nch) * H * 128 + h * 128, (int64_t)H * 128, nch, g, d);
+  red[0][tid] = merge_sum_mean<PER>(r, nch, g);
   __syncthreads();
   const float mean = sum16(red[0], d) / (float)nch;
-  red[1][tid] = merge_sum_m2(r, nch, g, (float)rows, mean);
+  red[1][tid] = merge_sum_m2<PER>(r, nch, g, (float)rows, mean);
   __syncthreads();
   if (g == 0) {
     const int64_t o = ((int64_t)set * H + h) * 64 + d;
@@ -579,13 +588,22 @@ __global__ void __launch_bounds__(1024) token_stats_partials_kernel(const float*
 }  // namespace
 
 hipError_t ir_launch_adain_affine_partials(const AdainPartialsKParams& p, hipStream_t s) {
-  hipLaunchKernelGGL(adain_affine_partials_kernel, dim3(p.B * p.N * p.H), dim3(1024), 0, s, p);
+  const int ns = p.Ls / p.style_rows, nc = p.content_ws != nullptr ? p.Lr / p.content_rows : 1;
+  const int nch = ns > nc ? ns : nc;                       // chunks per thread: 1 (<= 16 partials), 4 (<= 64), 16 (<= 256)
+  const dim3 grid(p.B * p.N * p.H), blk(1024);
+  if (nch <= 16) hipLaunchKernelGGL(adain_affine_partials_kernel<1>, grid, blk, 0, s, p);
+  else if (nch <= 64) hipLaunchKernelGGL(adain_affine_partials_kernel<4>, grid, blk, 0, s, p);
+  else hipLaunchKernelGGL(adain_affine_partials_kernel<kMergePerMax>, grid, blk, 0, s, p);
   return hipGetLastError();
 }
 
 hipError_t ir_launch_token_stats_partials(const float* ws, int rows, int nsets, int H, int len, float* mean, float* std, hipStream_t s) {
-  hipLaunchKernelGGL(token_stats_partials_kernel, dim3(nsets * H), dim3(1024), 0, s, ws, rows, H, len, mean, std);
+  const int nch = len / rows;
+  const dim3 grid(nsets * H), blk(1024);
+  if (nch <= 16) hipLaunchKernelGGL(token_stats_partials_kernel<1>, grid, blk, 0, s, ws, rows, H, len, mean, std);
+  else if (nch <= 64) hipLaunchKernelGGL(token_stats_partials_kernel<4>, grid, blk, 0, s, ws, rows, H, len, mean, std);
+  else hipLaunchKernelGGL(token_stats_partials_kernel<kMergePerMax>, grid, blk, 0, s, ws, rows, H, len, mean, std);
   return hipGetLastError();
 }
 
-int ir_adain_partials_max_chunks(void) { return 16 * kMergePer; }
+int ir_adain_partials_max_chunks(void) { return 16 * kMergePerMax; }

@@ -533,6 +533,10 @@ __global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKPa
   }
 }
 
+// (Round 4 also built this tile with a HALF-STAGE operand stream - stage laid out per K-half, one half issued in every load
+// phase, counted waits two load phases later: four phases of flight, issue cost balanced - bit-identical results, no faster:
+// profiles/r4_gemm_halfstage.txt.  Not kept.)
+
 // row panels per walk group: every XCD owns a contiguous range of tiles ordered GM row panels x all column tiles, so the
 // ~32 tiles resident on an XCD form a GM x (32 / GM) patch.  8 x 4 is the measured optimum of the patch shapes tried
 // (profiles/r4_pmc_linear_tiled.txt); IR_LIN_GM overrides it for such measurements

@@ -12,7 +12,7 @@ from instantrestore_amd import ops
 ITERS = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 LOAD = len(sys.argv) > 2 and sys.argv[2] == "1"
 SHAPES = [(8192, 1920, 640), (8192, 3840, 1280), (8192, 1280, 1280), (32768, 960, 320), (2048, 3840, 1280), (32768, 1920, 640), (8192, 640, 640)]
-KERNELS = ["auto", "256x256", "128x128", "128x256", "256x128", "64x128"]
+KERNELS = [k for k in os.environ.get("KERNELS", "auto,256x256,128x128,128x256,256x128,64x128").split(",")]
 side = torch.cuda.Stream()
 junk = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
 bad_total = 0

@@ -69,6 +69,27 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
         _lib.check(-1, "demo")
 
 
+def test_statistics_tail_entry_points_validate_without_a_gpu():
+    """ABI 6 (round 4): the q/k/v projection that leaves the AdaIN token statistics behind and the merges of its partials -
+    shape rules answered and bad arguments rejected before any launch"""
+    from instantrestore_amd import _lib
+    lib = _lib.lib()
+    # every projection kernel gives a wave 64 rows of Y: the statistics block; M must be whole blocks, N whole heads
+    assert lib.ir_linear_stats_rows(131072, 960, 320, 0) == 64 and lib.ir_linear_stats_rows(8192, 3840, 1280, 0) == 64
+    assert lib.ir_linear_stats_rows(2048, 3840, 1280, 0) == 64 and lib.ir_linear_stats_rows(100, 3840, 1280, 0) == 0
+    assert lib.ir_linear_stats_rows(8192, 96, 320, 0) == 0                       # N % 64 != 0
+    buf = (C.c_float * 16)()
+    ptr = C.cast(buf, C.c_void_p)
+    assert lib.ir_linear_fwd_stats(1, 0, 8192, 3840, 1280, ptr, 1280, ptr, 1280, None, ptr, 3840, 0, 1.0, 2560, 1280, None, 0, None) == -1
+    assert b"stats_ws" in lib.ir_last_error_string()
+    assert lib.ir_adain_affine_from_partials(8, 5, 4, 4096, 4096, None, 64, None, 64, None, None, None, 1e-5, ptr, ptr, None) == -1
+    assert lib.ir_adain_affine_from_partials(8, 5, 4, 4096, 4096, ptr, 60, ptr, 64, None, None, None, 1e-5, ptr, ptr, None) == -1   # 4096 % 60
+    assert lib.ir_adain_affine_from_partials(8, 5, 4, 4096, 4096, ptr, 64, None, 0, None, None, None, 1e-5, ptr, ptr, None) == -1   # no content statistics
+    assert lib.ir_adain_affine_from_partials(1, 5, 4, 65536, 65536, ptr, 64, ptr, 64, None, None, None, 1e-5, ptr, ptr, None) == -2  # > 256 partials per matrix
+    assert lib.ir_token_stats_from_partials(8, 5, 4096, None, 64, ptr, ptr, None) == -1
+    assert lib.ir_token_stats_from_partials(8, 5, 100, ptr, 64, ptr, ptr, None) == -1
+
+
 def test_variant_env_var_is_applied_at_load():
     """IR_ATTN_VARIANT=<n> selects a kernel variant for the whole process without code changes (the value rides
     in the per-call `tuning` field; the C library keeps no such state)"""

@@ -512,6 +512,7 @@ static int linear_fwd_impl(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n
     return fail(IR_ERR_UNSUPPORTED, "pointers must be 16-byte aligned");
   if ((int64_t)n * w_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "weight larger than 2 GiB");
   if (256 * x_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "x_ld too large");
+  if (256 * y_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "y_ld too large");   // a wave's 64 rows of Y sit behind one 32-bit buffer range
   LinearKParams p;
   p.x = x; p.w = w; p.bias = bias; p.y = y; p.x_ld = x_ld; p.w_ld = w_ld; p.y_ld = y_ld;
   p.M = (int32_t)m; p.N = n; p.K = k; p.nsplit = 1;

@@ -114,4 +114,12 @@ static __device__ __forceinline__ void buffer_load_lds16_async(i32x4 rsrc, unsig
                : "memory");
 }
 
+// 16-byte store through a buffer resource, issued from asm like the transfers above: byte address = base + voffset (per
+// lane; what the hardware range-checks against num_records: lanes past it are dropped) + soffset (wave-uniform, SGPR).
+// A kernel that sends every store of a wave through ONE per-lane offset keeps one register where per-store 64-bit
+// addresses were sixteen (linear_skinny.hip).  Counts in vmcnt like any store; hipcc's own waits only get stricter.
+static __device__ __forceinline__ void buffer_store16_async(i32x4 rsrc, u32x4 v, unsigned voffset, unsigned soffset) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(v), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+
 static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

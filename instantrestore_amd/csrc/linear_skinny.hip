@@ -98,9 +98,10 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
       if (s < KS) buffer_load_lds16_async(wrw, smem + slot * CHUNK_BYTES + s * SUB_BYTES + wq * 1024, off + s * 128);
     }
   };
-  int wread[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) wread[ks] = lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4);
+  // fragment ks of a sub-tile sits at lq * 128 + (((2 ks + hi) ^ swz) << 4) = wread0 ^ (ks << 5): ONE register, re-derived
+  // per chunk behind an opaque statement - four hoisted addresses were the registers that tipped the K = 320 kernel into a
+  // scratch reload inside this loop (and every scratch reload waits for vmcnt(0): the Y stores in flight)
+  int wread0 = lq * 128 + ((hi ^ ((lq >> 1) & 7)) << 4);
 
   if (BIAS)
     for (int i = tid; i < (c_end - c_begin) * NCH; i += NT) sbias[i] = ((const T*)p.bias)[c_begin * NCH + i];
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
       f32x4 f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) f[i] = acc[4 * g + i] * cs;
-      if (BIAS) {
+      if (BIAS && n0 < p.scale_cols) {   // scaled columns: (sum) * cs + bias; everywhere else the accumulators STARTED at the bias
         const v4 bv = *(const v4*)(sbias + (n0 - c_begin * NCH) + 8 * g + 4 * hi);
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] += (float)bv[i];
@@ -133,25 +134,28 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
       *(v4*)(tb + (rbase + lq) * TPITCH + half * 64 + (8 * g + 4 * hi) * 2) = __builtin_convertvector(f, v4);
     }
   };
-  // rows past M were loaded as copies of row M-1 and therefore hold row M-1's exact result: they are
-  // stored there too (same bytes), which keeps the number of stores per iteration constant - the
-  // s_waitcnt arithmetic of the main loop counts them
+  // Stores go through a buffer resource over THIS wave's rows of Y: one per-lane byte offset (row r of 8 j + (lane >> 3),
+  // 16-byte column slot lane & 7) serves every store - the j and column terms are wave-uniform and ride in the scalar
+  // offset - and rows past M fall outside num_records, where the hardware drops them.  (Rounds 1-3 held eight clamped
+  // 64-bit row addresses in sixteen registers across the main loop; with them the K = 320 kernels spilled X fragments.)
+  // Dropped or not, a store counts in vmcnt: the s_waitcnt arithmetic of the main loop relies on eight per chunk pair.
   const int row0 = mb * NT + wid * 64;
+  const int rows_here = (p.M - row0) < 64 ? (p.M - row0) : 64;   // >= 1: the grid covers ceil(M / NT) blocks, a wave past M has none
+  const i32x4 yrw = make_rsrc_words((const T*)p.y + (int64_t)row0 * p.y_ld,
+                                    rows_here > 0 ? (unsigned)((((int64_t)rows_here - 1) * p.y_ld + p.N) * 2) : 0u);
+  const unsigned ystep = (unsigned)(p.y_ld * 16);   // 8 rows down, in bytes
+  unsigned yvo = (unsigned)((lane >> 3) * p.y_ld * 2 + (lane & 7) * 16);
   auto store_full = [&](int j, int n0) {   // 8 rows x 128 B: one of the eight stores of a finished chunk PAIR
     ir_wave_lds_fence();                   // rows staged by other lanes (ir_common.h)
     const int r = 8 * j + (lane >> 3);
     const u32x4 v = *(const u32x4_alias*)(tb + r * TPITCH + (lane & 7) * 16);
-    const int row = row0 + r;
-    T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 7) * 8;
-    *(u32x4*)yp = v;
+    buffer_store16_async(yrw, v, yvo + (unsigned)j * ystep, (unsigned)n0 * 2);
   };
   auto store_half = [&](int j, int n0) {   // 16 rows x 64 B (left half of the tile): a range's odd last chunk
     ir_wave_lds_fence();
     const int r = 16 * j + (lane >> 2);
     const u32x4 v = *(const u32x4_alias*)(tb + r * TPITCH + (lane & 3) * 16);
-    const int row = row0 + r;
-    T* yp = (T*)p.y + (int64_t)(row < p.M ? row : p.M - 1) * p.y_ld + n0 + (lane & 3) * 8;
-    *(u32x4*)yp = v;
+    buffer_store16_async(yrw, v, (unsigned)(r * p.y_ld * 2 + (lane & 3) * 16), (unsigned)n0 * 2);
   };
 
   // Iteration i: start the transfer of chunk i+1, put chunk i-1's results into its half of the staging tile and - when
@@ -169,11 +173,28 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
     }
     const bool pair_done = i > 0 && (i & 1) == 0;   // chunks i-2, i-1 are both in the tile
     const unsigned char* Wb = smem + cur * CHUNK_BYTES;
+    if (BIAS && c * NCH >= p.scale_cols) {
+      // the bias is the accumulators' starting value (a lane's registers walk along n): no add, no bias registers live while
+      // a finished chunk is staged - with them the K = 320 kernel reloaded a resident X fragment from scratch in every
+      // iteration since round 2, and a scratch reload waits for vmcnt(0), i.e. for the Y stores in flight
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+      for (int g = 0; g < 4; ++g) {
+        const v4 bv = *(const v4*)(sbias + (c - c_begin) * NCH + 8 * g + 4 * hi);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accA[4 * g + i] = accB[4 * g + i] = (float)bv[i];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accA[r] = 0.f; accB[r] = 0.f; }
+    }
+    if (BIAS) __builtin_amdgcn_sched_barrier(0);   // the bias reads retire before the W fragment reads start (registers)
     // W fragments double-buffered by 64-k sub-tile: the four reads of sub-tile s+1 are in flight while the
     // eight MFMAs of sub-tile s issue
     v8 wf[2][4];
+    asm volatile("" : "+v"(wread0));
+    int wread[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) wread[ks] = wread0 ^ (ks << 5);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) wf[0][ks] = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Wb + wread[ks]);
 #pragma unroll

@@ -208,10 +208,10 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         "traffic": _pmc_traffic_bytes() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
         "traffic_static": True,      # read from the committed PMC pass named below, NOT measured in this run (counters need rocprofv3)
         "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)" % _pmc_profile_name(),
-        "power_note": "this kernel runs at the 1400 W board cap on random data (profiles/r2_power_probe.txt, "
-                      "r2_power_probe_postcheck.txt): sustained shader clock 2.2-2.25 GHz against the 2.4 GHz the peak assumes "
-                      "(0.894 ms at the cap vs 0.694 ms on all-zero inputs at full clock); an MFMA-only stream of the same instruction "
-                      "holds 1.75-1.8 PFLOP/s on random operands under that cap in the round-2 probes (profiles/r2_kernel_experiments.txt)",
+        "power_note": "this kernel runs at the 1400 W board cap on random data (profiles/r4_energy_attn.txt): 1.10 J per launch = "
+                      "1.28 pJ/flop at 1386 W and 2.10 GHz against the 2.4 GHz the peak assumes; 0.65 J on all-zero inputs at full clock, the "
+                      "same 1.66 M cycles; an MFMA-only stream of the same instruction holds 1.96 PFLOP/s on random operands under that "
+                      "cap (profiles/r1_ubench_mfma_power.txt, r4_ubench_mfma_reuse.txt)",
     }
 
 

@@ -146,6 +146,19 @@ def shared_attn_processor_np(hidden, wq, wk, wv, wo, bo, ref_k, ref_v, heads,
     return (out, probs, (q, k, v)) if return_probs else out
 
 
+def faceid_processor_np(hidden, wq, wo, bo, wp, bp, wk, wv, heads, encoder_hidden=None, dtype=np.float64):
+    """``FaceIDAttnProcessor.forward`` (attn_processors.py:115-180): queries from ``attn.to_q``; keys and values from the
+    processor's own ``face_projection`` (with bias) followed by ``to_k_face_embed`` / ``to_v_face_embed`` (no bias) applied to
+    the encoder states - or to the hidden states themselves when there are none (:148-153); plain softmax attention
+    (:159-161), ``to_out[0]`` (:164).  No reference K/V, no AdaIN: ``ref_keys`` / ``ref_values`` are ignored (:123-124)."""
+    c = lambda t: np.asarray(t, dtype=dtype)
+    hidden = c(hidden)
+    src = (hidden if encoder_hidden is None else c(encoder_hidden)) @ c(wp).T + c(bp)
+    q, k, v = hidden @ c(wq).T, src @ c(wk).T, src @ c(wv).T
+    core = shared_attention_np(q, k, v, None, None, heads, (q.shape[-1] // heads) ** -0.5, False, True, dtype)
+    return core @ c(wo).T + c(bo)
+
+
 def zero_fill_invalid_np(ref: np.ndarray, valid_indices) -> np.ndarray:
     """pix2pix_turbo.py:269-273: refs >= valid_indices[b] are ZEROED (not masked)."""
     out = ref.copy()

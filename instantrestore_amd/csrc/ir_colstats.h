@@ -116,6 +116,63 @@ static __device__ __forceinline__ void ir_wave_col_stats(const T* __restrict__ y
   }
 }
 
+// One wave: partial of ONE head from a 64-row x 64-column block of finished 16-bit outputs that sits in LDS (row pitch `pitch`
+// bytes), e.g. the staging tile of the X-stationary kernels right after a chunk pair has left.  Same sums in the same order as
+// ir_stats_first / _add / _finish (shift = row 0, rows rs + 8 j, butterfly over lane bits 3..5) - the same bits - but built
+// for a kernel with ~35 registers to spare: four columns at a time, rows in a rolled loop (12 accumulators + 6 temporaries).
+template <typename T>
+static __device__ __forceinline__ void ir_lds_block_stats(const unsigned char* tb, int pitch, float* __restrict__ wsp) {
+  using v4 = typename ElemTraits<T>::v4;
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2), may_alias));
+  int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(lane));
+  const int cs = lane & 7, rs = lane >> 3;
+#pragma nounroll
+  for (int half = 0; half < 2; ++half) {
+    const unsigned char* src = tb + rs * pitch + cs * 16 + half * 8;
+    float K[4], s1[4], s2[4];
+    {
+      const f32x4 f = __builtin_convertvector(__builtin_bit_cast(v4, *(const u32x2_*)src), f32x4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        K[i] = __shfl(f[i], cs);
+        const float d = f[i] - K[i];
+        s1[i] = d;
+        s2[i] = d * d;
+      }
+    }
+#pragma nounroll
+    for (int j = 1; j < 8; ++j) {
+      const f32x4 f = __builtin_convertvector(__builtin_bit_cast(v4, *(const u32x2_*)(src + 8 * j * pitch)), f32x4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float d = f[i] - K[i];
+        s1[i] += d;
+        s2[i] = __builtin_fmaf(d, d, s2[i]);
+      }
+    }
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s1[i] += __shfl_xor(s1[i], m);
+        s2[i] += __shfl_xor(s2[i], m);
+      }
+    }
+    if (rs == 0) {
+      f32x4 mean, m2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        mean[i] = K[i] + s1[i] * (1.0f / kStatsRows);
+        m2[i] = fmaxf(s2[i] - s1[i] * s1[i] * (1.0f / kStatsRows), 0.f);
+      }
+      float* o = wsp + cs * 8 + half * 4;
+      *(f32x4*)o = mean;
+      *(f32x4*)(o + 64) = m2;
+    }
+  }
+}
+
 // heads [lo, hi) of the statistics range that lie inside columns [n0, n1) (all multiples of 64)
 static __device__ __forceinline__ void ir_stats_heads(int st_col0, int st_cols, int n0, int n1, int& lo, int& hi) {
   const int a = n0 - st_col0, b = n1 - st_col0, nh = st_cols >> 6;

@@ -158,6 +158,15 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
     buffer_store16_async(yrw, v, (unsigned)(r * p.y_ld * 2 + (lane & 3) * 16), (unsigned)n0 * 2);
   };
 
+  // statistics of one finished pair = one head of this wave's 64 rows (see the end of the loop body)
+  const bool st_on = p.st_ws != nullptr;
+  auto pair_stats = [&](int n0) {
+    if (n0 < p.st_col0 || n0 >= p.st_col0 + p.st_cols) return;   // wave-uniform
+    ir_wave_lds_fence();
+    ir_lds_block_stats<T>(tb, TPITCH, p.st_ws + ((int64_t)(row0 / kStatsRows) * (p.st_cols >> 6) + ((n0 - p.st_col0) >> 6)) * 128);
+    ir_wave_lds_fence();
+  };
+
   // Iteration i: start the transfer of chunk i+1, put chunk i-1's results into its half of the staging tile and - when
   // that completes a pair (i even) - send the pair on its way in eight stores issued BETWEEN the MFMA groups of chunk i
   // (a write path running at HBM speed back-pressures the issuing wave: eight stores in a row stall it and its lockstep
@@ -217,6 +226,12 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    // token statistics of the pair that has just left (round 4, ir_colstats.h): its 64 x 64 block is still in the staging
+    // tile, and the W-fragment registers are free until the next chunk - the statistics cost neither a register across the
+    // loop nor a byte of memory traffic (the first form re-read the wave's stores after the loop: 84 MB back from the
+    // Infinity Cache on the 131072-row projection, +17 us).  Whole heads only: pairs start on multiples of 64 columns.
+    if (pair_done && st_on) pair_stats((c - 2) * NCH);
+    // the statistics' four stores were issued after the pair's eight: the count below only gets stricter with them
     if (pair_done) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -226,20 +241,12 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
     stage_block(accB, 32, (c_end - 1) * NCH, 1);
 #pragma unroll
     for (int j = 0; j < 8; ++j) store_full(j, (c_end - 2) * NCH);
+    if (st_on) pair_stats((c_end - 2) * NCH);
   } else {                // odd number of chunks in this range: the last one leaves alone, in half lines
     stage_block(accA, 0, (c_end - 1) * NCH, 0);
     stage_block(accB, 32, (c_end - 1) * NCH, 0);
 #pragma unroll
     for (int j = 0; j < 4; ++j) store_half(j, (c_end - 1) * NCH);
-  }
-  // ---- tail (round 4): token statistics of the V columns this wave has just written (ir_colstats.h) -----------------
-  if (p.st_ws != nullptr) {
-    int head_lo, head_hi;
-    ir_stats_heads(p.st_col0, p.st_cols, c_begin * NCH, c_end * NCH, head_lo, head_hi);   // column ranges are whole heads here
-    if (head_lo < head_hi) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of its 64 rows have left
-      ir_wave_col_stats<T, 5>((const T*)p.y, p.y_ld, row0, head_lo, head_hi, p.st_ws, p.st_col0, p.st_cols);
-    }
   }
 }
 

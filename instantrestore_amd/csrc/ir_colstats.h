@@ -119,7 +119,7 @@ static __device__ __forceinline__ void ir_wave_col_stats(const T* __restrict__ y
 // One wave: partial of ONE head from a 64-row x 64-column block of finished 16-bit outputs that sits in LDS (row pitch `pitch`
 // bytes), e.g. the staging tile of the X-stationary kernels right after a chunk pair has left.  Same sums in the same order as
 // ir_stats_first / _add / _finish (shift = row 0, rows rs + 8 j, butterfly over lane bits 3..5) - the same bits - but built
-// for a kernel with ~35 registers to spare: four columns at a time, rows in a rolled loop (12 accumulators + 6 temporaries).
+// for a kernel with ~35 registers to spare: four columns at a time, rows in groups of 3-4 (12 accumulators + ~16 temporaries).
 template <typename T>
 static __device__ __forceinline__ void ir_lds_block_stats(const unsigned char* tb, int pitch, float* __restrict__ wsp) {
   using v4 = typename ElemTraits<T>::v4;
@@ -141,14 +141,22 @@ static __device__ __forceinline__ void ir_lds_block_stats(const unsigned char* t
         s2[i] = d * d;
       }
     }
-#pragma nounroll
-    for (int j = 1; j < 8; ++j) {
-      const f32x4 f = __builtin_convertvector(__builtin_bit_cast(v4, *(const u32x2_*)(src + 8 * j * pitch)), f32x4);
+    // rows 1-3, then 4-7: the loads of a group in flight together (one LDS round trip per group, not per row); same order of sums
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float d = f[i] - K[i];
-        s1[i] += d;
-        s2[i] = __builtin_fmaf(d, d, s2[i]);
+    for (int j0 = 1; j0 < 8; j0 += (j0 == 1 ? 3 : 4)) {
+      const int nj = j0 == 1 ? 3 : 4;
+      u32x2_ raw[4];
+#pragma unroll
+      for (int jj = 0; jj < nj; ++jj) raw[jj] = *(const u32x2_*)(src + 8 * (j0 + jj) * pitch);
+#pragma unroll
+      for (int jj = 0; jj < nj; ++jj) {
+        const f32x4 f = __builtin_convertvector(__builtin_bit_cast(v4, raw[jj]), f32x4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d = f[i] - K[i];
+          s1[i] += d;
+          s2[i] = __builtin_fmaf(d, d, s2[i]);
+        }
       }
     }
 #pragma unroll

@@ -529,5 +529,7 @@ hipError_t launch(const LinearKParams& p0, hipStream_t s) {
 }  // namespace
 
 hipError_t ir_launch_linear_skinny(const LinearKParams& p, int dtype, hipStream_t s) {
+  // this development copy predates round 4's statistics (ir_colstats.h): refuse rather than leave the workspace unwritten
+  if (p.st_ws != nullptr) return hipErrorNotSupported;
   return dtype == 1 ? launch<__bf16>(p, s) : launch<_Float16>(p, s);
 }

@@ -972,6 +972,20 @@ def main():
             roof["at_measured_clock"] = {"sclk_mhz": pw["sclk_mhz_avg"], "watts": pw["watts_avg"], "peak_at_clock": round(pk, 1),
                                          "frac_at_clock": round(roof["achieved"] / pk, 4),
                                          "note": "step-average clock under the 1400 W cap; not the contract's frac"}
+        if roof:
+            # what the matrix pipe itself sustains on THIS box under the board's power cap, measured now (ir_bench_mfma_stream: an
+            # MFMA-only stream of the kernel's instruction, ~0.15 s per setting): the contract's `peak` is the 2.4 GHz figure,
+            # which random operands never see.  Informational: `frac` stays achieved / peak.
+            try:
+                from instantrestore_amd import ops as _o
+                cap_r = _o.bench_mfma_stream(dtype, zero_operands=False, device=dev)
+                cap_z = _o.bench_mfma_stream(dtype, zero_operands=True, device=dev)
+                roof["at_power_cap"] = {"mfma_only_tflops_random_operands": round(cap_r, 1), "mfma_only_tflops_zero_operands": round(cap_z, 1),
+                                        "frac_of_sustained": round(roof["achieved"] / cap_r, 4),
+                                        "note": "MFMA-only stream of v_mfma_f32_32x32x16 (two waves per SIMD, every CU) measured in this run; "
+                                                "on random operands the 1400 W cap sets it, on zeros the clock does; not the contract's frac"}
+            except Exception as e:   # a measurement aid must not cost the line
+                roof["at_power_cap"] = {"error": "%s: %s" % (type(e).__name__, e)}
         line = {
             "metric": "restored images/sec @512px, 4 refs, single-step; 1/2/4/8 MI355X",
             "metric_note": "one step = one pass of the HOT PATH only (attention path of both UNets, SURVEY 8a a-1..a-4): "

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IR_ABI_VERSION 6
+#define IR_ABI_VERSION 7
 #define IR_HEAD_DIM 64
 
 typedef enum ir_status {
@@ -372,6 +372,19 @@ const char* ir_last_error_string(void);    /* thread-local, never NULL */
  * *ms_per_launch (bench.py's live roofline measurement; synchronises the stream).
  */
 int ir_time_shared_attn_fwd(const ir_shared_attn_args* args, int32_t iters, void* stream, float* ms_per_launch);
+
+/*
+ * ir_bench_mfma_stream (ABI v7) - what the matrix pipe SUSTAINS on this device: `launches` back-to-back launches of an
+ * MFMA-only stream of the attention kernels' instruction (v_mfma_f32_32x32x16 of `dtype`; two waves per SIMD on every CU,
+ * iters x 16 MFMAs per wave, pseudo-random operands or - zero_operands != 0 - all zeros), bracketed by HIP events on
+ * `stream`; returns the TFLOP/s of the bracketed launches in *tflops (synchronises the stream).  `scratch`: device memory,
+ * >= ir_bench_mfma_stream_scratch_bytes().  Give it >= 0.1 s in all (e.g. iters 40000, launches 5) so that the board's
+ * power controller settles: on random operands the 1400 W cap, not the 2.4 GHz of the datasheet peak, sets the result
+ * (bench.py `roofline.at_power_cap`).  No reference counterpart: measurement only.
+ */
+size_t ir_bench_mfma_stream_scratch_bytes(void);
+int ir_bench_mfma_stream(int32_t dtype, int32_t zero_operands, int32_t iters, int32_t launches, void* scratch, size_t scratch_bytes,
+                         void* stream, float* tflops);
 
 #ifdef __cplusplus
 }

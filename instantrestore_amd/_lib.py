@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # IR_LIB_PATH: load an alternative build of the same ABI (compiler-flag A/B experiments)
 LIB_PATH = os.environ.get("IR_LIB_PATH") or os.path.join(_HERE, "libinstantrestore_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 IR_DTYPE_F16, IR_DTYPE_BF16 = 0, 1
 IR_FLAG_INCLUDE_SELF, IR_FLAG_Q_PRESCALED, IR_FLAG_OUT_F32 = 1, 2, 4
@@ -53,6 +53,8 @@ SYMBOLS = {
     "ir_shared_attn_fwd": (C.c_int, [C.POINTER(SharedAttnArgs), vp]),
     "ir_shared_attn_kernel_name": (C.c_char_p, [C.POINTER(SharedAttnArgs)]),
     "ir_time_shared_attn_fwd": (C.c_int, [C.POINTER(SharedAttnArgs), i32, vp, C.POINTER(f32)]),
+    "ir_bench_mfma_stream_scratch_bytes": (C.c_size_t, []),
+    "ir_bench_mfma_stream": (C.c_int, [i32, i32, i32, i32, vp, C.c_size_t, vp, C.POINTER(f32)]),
     "ir_attn_probs": (C.c_int, [C.POINTER(SharedAttnArgs), vp, vp]),
     "ir_adain_stats_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32]),
     "ir_adain_stats": (C.c_int, [i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, vp, i64, i64, i64, i64,

@@ -6,7 +6,7 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${IR_OUT:-${HERE}/../libinstantrestore_hip.so}"
 BUILD_DIR="${IR_BUILD_DIR:-build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=(linear_tiled.hip shared_attn_fwd.hip shared_attn_fwd_pipe.hip shared_attn_fwd_w64.hip attn_probs.hip adain.hip image_io.hip linear_skinny.hip c_abi.hip)
+SRCS=(linear_tiled.hip shared_attn_fwd.hip shared_attn_fwd_pipe.hip shared_attn_fwd_w64.hip attn_probs.hip adain.hip image_io.hip linear_skinny.hip bench_hooks.hip c_abi.hip)
 cd "${HERE}"
 OBJS=()
 pids=()

@@ -157,6 +157,39 @@ int ir_time_shared_attn_fwd(const ir_shared_attn_args* args, int32_t iters, void
   return IR_OK;
 }
 
+static int bench_blocks() {   // one 8-wave workgroup per CU = two waves per SIMD
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  return cus;
+}
+
+size_t ir_bench_mfma_stream_scratch_bytes(void) { return (size_t)1024 * 512 * sizeof(float); }   // up to 1024 CUs
+
+int ir_bench_mfma_stream(int32_t dtype, int32_t zero_operands, int32_t iters, int32_t launches, void* scratch, size_t scratch_bytes,
+                         void* stream, float* tflops) {
+  if (dtype != IR_DTYPE_F16 && dtype != IR_DTYPE_BF16) return fail(IR_ERR_UNSUPPORTED, "dtype %d: fp16 (0) / bf16 (1)", dtype);
+  if (iters <= 0 || launches <= 0 || tflops == nullptr || scratch == nullptr) return fail(IR_ERR_INVALID_ARG, "iters/launches/scratch/tflops");
+  const int blocks = bench_blocks();
+  if (blocks > 1024 || scratch_bytes < (size_t)blocks * 512 * sizeof(float)) return fail(IR_ERR_WORKSPACE, "scratch %zu < %zu bytes", scratch_bytes, (size_t)blocks * 512 * sizeof(float));
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fail(IR_ERR_LAUNCH, "hipEventCreate failed");
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; ++i) e = ir_launch_bench_mfma_stream(dtype, zero_operands, iters, blocks, (float*)scratch, s);   // untimed: clocks settle
+  if (e == hipSuccess) e = hipEventRecord(e0, s);
+  for (int i = 0; i < launches && e == hipSuccess; ++i) e = ir_launch_bench_mfma_stream(dtype, zero_operands, iters, blocks, (float*)scratch, s);
+  if (e == hipSuccess) e = hipEventRecord(e1, s);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "mfma stream: %s", hipGetErrorString(e));
+  const double flops = (double)launches * iters * 16.0 * 32768.0 * (double)blocks * 8.0;   // 2 * 32 * 32 * 16 per MFMA, 8 waves per workgroup
+  *tflops = (float)(flops / ((double)ms * 1e-3) / 1e12);
+  return IR_OK;
+}
+
 int ir_attn_probs(const ir_shared_attn_args* args, void* probs, void* stream) {
   AttnKParams p;
   const int rc = build_attn_params(args, &p, false);

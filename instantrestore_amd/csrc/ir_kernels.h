@@ -132,6 +132,8 @@ struct AdainPartialsKParams {
 };
 hipError_t ir_launch_adain_affine_partials(const AdainPartialsKParams& p, hipStream_t s);
 hipError_t ir_launch_token_stats_partials(const float* ws, int rows, int nsets, int H, int len, float* mean, float* std, hipStream_t s);
+// benchmark hook (bench_hooks.hip): one launch of an MFMA-only stream, `blocks` workgroups x 8 waves x iters x 16 MFMAs
+hipError_t ir_launch_bench_mfma_stream(int dtype, int zero, int iters, int blocks, float* out, hipStream_t s);
 int ir_adain_partials_max_chunks(void);   // partials per matrix the merge kernels hold in registers (len / rows <= this)
 hipError_t ir_launch_adain_apply(const AdainApplyKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_zero_refs(const ZeroRefsKParams& p, hipStream_t s);

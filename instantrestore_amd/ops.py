@@ -231,6 +231,22 @@ def time_shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: i
     return float(ms.value)
 
 
+def bench_mfma_stream(dtype: torch.dtype = torch.bfloat16, zero_operands: bool = False, iters: int = 40000, launches: int = 5,
+                      device: Optional[torch.device] = None) -> float:
+    """TFLOP/s an MFMA-only stream of the attention kernels' instruction sustains on this device (``ir_bench_mfma_stream``):
+    on pseudo-random operands the board's power cap sets it, on all-zero operands the clock does.  Measurement only."""
+    dev = device or torch.device("cuda", torch.cuda.current_device())
+    if dev.type != "cuda":
+        raise RuntimeError("bench_mfma_stream needs the GPU (no CPU fallback)")
+    with torch.cuda.device(dev):
+        nbytes = int(_lib.lib().ir_bench_mfma_stream_scratch_bytes())
+        scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+        out = C.c_float(0.0)
+        _lib.check(_lib.lib().ir_bench_mfma_stream(_DT[dtype], 1 if zero_operands else 0, int(iters), int(launches), scratch.data_ptr(),
+                                                   nbytes, _stream(), C.byref(out)), "ir_bench_mfma_stream")
+    return float(out.value)
+
+
 def shared_attention_kernel_name(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
                                  include_self: bool = True, adain=None, q_prescaled: bool = False) -> str:
     """which kernel the dispatcher launches for these tensors (reporting only)"""

@@ -101,3 +101,18 @@ def test_variant_env_var_is_applied_at_load():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, r.stderr
     assert r.stdout.strip().splitlines()[-1] == "11"
+
+
+def test_mfma_stream_hook_validates_without_a_gpu():
+    """ir_bench_mfma_stream (ABI v7, bench.py `roofline.at_power_cap`) refuses bad arguments before it touches the device"""
+    from instantrestore_amd import _lib
+    lib = _lib.lib()
+    out = C.c_float(0.0)
+    need = int(lib.ir_bench_mfma_stream_scratch_bytes())
+    assert need >= 256 * 512 * 4
+    fake = C.c_void_p(1 << 20)      # never dereferenced: every call below fails validation
+    assert lib.ir_bench_mfma_stream(1, 0, 0, 1, fake, need, None, C.byref(out)) == -1        # IR_ERR_INVALID_ARG: iters
+    assert lib.ir_bench_mfma_stream(1, 0, 10, 0, fake, need, None, C.byref(out)) == -1       # launches
+    assert lib.ir_bench_mfma_stream(1, 0, 10, 1, None, need, None, C.byref(out)) == -1       # scratch
+    assert lib.ir_bench_mfma_stream(7, 0, 10, 1, fake, need, None, C.byref(out)) == -2       # IR_ERR_UNSUPPORTED: dtype
+    assert lib.ir_bench_mfma_stream(1, 0, 10, 1, fake, 16, None, C.byref(out)) == -4         # IR_ERR_WORKSPACE

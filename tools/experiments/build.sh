@@ -20,7 +20,7 @@ CSRC="${HERE}/../../instantrestore_amd/csrc"
 OUT="${IR_OUT:-${HERE}/libinstantrestore_hip_dev.so}"
 BUILD_DIR="${IR_BUILD_DIR:-${HERE}/build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-PRODUCT=(linear_tiled.hip shared_attn_fwd.hip shared_attn_fwd_pipe.hip attn_probs.hip adain.hip image_io.hip c_abi.hip)
+PRODUCT=(linear_tiled.hip shared_attn_fwd.hip shared_attn_fwd_pipe.hip attn_probs.hip adain.hip image_io.hip bench_hooks.hip c_abi.hip)
 DEV=(shared_attn_fwd_w64_dev.hip linear_skinny_dev.hip linear_xs_pp.hip linear_xs_rot.hip shared_attn_fwd_sp.hip shared_attn_fwd_tp.hip shared_attn_fwd_pp.hip)
 mkdir -p "${BUILD_DIR}"
 OBJS=(); pids=()

@@ -303,6 +303,27 @@ def kernel_class_breakdown(layers, B, N, steps):
             row["flop_per_byte"] = round(f / b, 1)
             row["frac_of_roofline"] = round(max(t_mfma, t_hbm) * 1e3 / v, 4)
         out[k] = row
+    # context for the HBM-bound classes: what a plain device-to-device copy sustains on this box right now (1 GiB read +
+    # 1 GiB written per pass; the guide's 8 TB/s is the pin rate) - informational, next to the contract's frac_of_hbm_peak
+    try:
+        src = torch.empty(1 << 28, dtype=torch.float32, device=layers[0]["h_main"].device)
+        dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 8 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+        for row in out.values():
+            if row.get("bound") == "hbm":
+                row["frac_of_measured_copy"] = round(row["gb_per_s"] / copy_gbs, 4)
+        out["_hbm_copy_gb_per_s_measured"] = round(copy_gbs, 1)
+    except Exception:
+        pass
     out["_reconciliation"] = {"classes_sum_ms": round(allms * scale / steps, 4), "one_stream_step_ms_plain": round(t_plain, 4),
                               "one_stream_step_ms_with_events": round(t_instr, 4), "scale_applied": round(scale, 4),
                               "note": "class times = HIP-event times x (plain step / instrumented step): the event pairs cost the "

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(NW * 64, 2) linear_skinny_kernel(const LinearK
   };
 
   // statistics of one finished pair = one head of this wave's 64 rows (see the end of the loop body)
-  const bool st_on = p.st_ws != nullptr;
+  const bool st_on = p.st_ws != nullptr && row0 < p.M;   // M is whole 64-row blocks then: a wave past M has no block (and no slot in st_ws)
   auto pair_stats = [&](int n0) {
     if (n0 < p.st_col0 || n0 >= p.st_col0 + p.st_cols) return;   // wave-uniform
     ir_wave_lds_fence();
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(512, 2) linear_ksplit_kernel(const LinearKPara
     for (int j = 0; j < 4; ++j) store_part(j, par, n0);
   }
   // ---- tail (round 4): token statistics of the V columns this wave has just written (ir_colstats.h) -----------------
-  if (p.st_ws != nullptr && kh == 0) {
+  if (p.st_ws != nullptr && kh == 0 && row0 < p.M) {   // waves past M (M % 256 != 0) have no block and no slot in st_ws
     int head_lo, head_hi;
     ir_stats_heads(p.st_col0, p.st_cols, c_begin * NCH, c_end * NCH, head_lo, head_hi);   // the launcher aligns column ranges to 64 then
     if (head_lo < head_hi) {

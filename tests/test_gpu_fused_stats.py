@@ -142,3 +142,32 @@ def test_the_step_launches_no_statistics_pass_and_keeps_its_outputs():
     assert calls["adain_stats"] == calls["adain_stats_cached"] == calls["token_stats"] == 0, calls
     # one launch per shared layer merges both sides' partials into the affine; nothing is launched on the capture side
     assert calls["affine"] == 18 and calls["tsp"] == 0, calls
+
+
+@pytest.mark.parametrize("C_", [320, 640], ids=["K320", "K640"])
+def test_row_count_that_leaves_waves_without_a_block_writes_no_partial_out_of_range(C_):
+    """M = 65600 = 1025 blocks of 64 rows: whole statistics blocks, but not whole 256-row workgroups of the X-stationary kernels -
+    the last workgroup has three waves past M.  They own no block and no slot in the workspace: the canary behind the
+    workspace must survive, and the partials must still merge to the statistics of the rounded V."""
+    import ctypes as C
+    from instantrestore_amd import _lib, ops
+    H = C_ // 64
+    sets, L = 1025, 64
+    M = sets * L
+    g = torch.Generator().manual_seed(99 + C_)
+    w = (torch.randn(3 * C_, C_, generator=g) / C_ ** 0.5).to(torch.bfloat16).cuda()
+    x = torch.randn(M, C_, generator=g).cuda()
+    assert ops.linear_kernel_for(M, 3 * C_, C_, False) == 1 and ops.linear_stats_rows(M, 3 * C_, C_, False) == 64   # X-stationary
+    need = (M // 64) * H * 128
+    ws = torch.full((need + 8192,), 12345.0, dtype=torch.float32, device="cuda")
+    y = torch.empty(M, 3 * C_, dtype=torch.bfloat16, device="cuda")
+    rc = _lib.lib().ir_linear_fwd_stats(1, 1, M, 3 * C_, C_, x.data_ptr(), C_, w.data_ptr(), C_, None, y.data_ptr(), 3 * C_, 0, 1.0,
+                                        2 * C_, C_, ws.data_ptr(), need * 4, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, _lib.lib().ir_last_error_string()
+    torch.cuda.synchronize()
+    assert bool((ws[need:] == 12345.0).all()), "a partial was written behind the workspace"
+    st = ops.ColumnStats(ws[:need].view(M // 64, H, 128), 64, H)
+    m1, s1 = ops.token_stats_from_partials(st, sets, L)
+    v = y[:, 2 * C_:].reshape(sets, L, H, 64).float()
+    assert torch.equal(y, ops.linear(x, w, None))
+    assert _rel(m1.cpu(), v.mean(1).cpu()) <= 1e-5 and _rel(s1.cpu(), v.std(1, unbiased=True).cpu()) <= 1e-5

@@ -530,6 +530,8 @@ def adain_affine_from_partials(style: ColumnStats, batch: int, len_self: int, n_
             raise ValueError(f"content statistics must be contiguous fp32 ({batch}, {n_refs}, {H}, 64)")
     if style.ws.shape[0] * style.rows != batch * len_self or (content is not None and content.ws.shape[0] * content.rows != batch * n_refs * len_ref):
         raise ValueError("partials do not cover batch x len rows")
+    if valid is not None and (valid.dtype != torch.int32 or valid.device != dev or valid.numel() != batch or not valid.is_contiguous()):
+        raise ValueError(f"valid must be a contiguous int32 ({batch},) tensor on {dev}")
     a = torch.empty((batch, n_refs, H, HEAD_DIM), dtype=torch.float32, device=dev)
     b = torch.empty_like(a)
     rc = _lib.lib().ir_adain_affine_from_partials(

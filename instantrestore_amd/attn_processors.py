@@ -151,8 +151,24 @@ def _project_qkv(attn, st: _Prepared, want_stats: bool = False):
     multiply-add per score.  Shapes that go to the vendor GEMM keep the plain q."""
     src = _kv_source(attn, st)
     tq, tk, tv = attn.to_q, attn.to_k, attn.to_v
-    if st.encoder is not None or torch.is_grad_enabled():
+    if torch.is_grad_enabled():
         return tq(st.hidden), tk(src), tv(src), False, None
+    if st.encoder is not None:
+        # cross attention (the f-1 layers, attn_processors.py:224-230 with encoder_hidden_states): q from the image tokens,
+        # k / v from the text states - different inputs, so no q/k/v fusion, but still this library's GEMMs (round 4: the
+        # tiny-M shapes lead the vendor GEMM + its cast pass, profiles/r4_gemm_probe_small.txt) and ONE GEMM for k and v
+        q = _project_single(attn, "_ir_q_cache", "_ir_q_bias_cache", tq, st.hidden)
+        ek, ev = _lora.effective_linear(tk), _lora.effective_linear(tv)
+        if ek is not None and ev is not None and ek[0].bias is None and ev[0].bias is None and ek[0].weight.shape == ev[0].weight.shape:
+            dtype = _autocast_or(ek[0].weight, src)
+            w = _lora.cached_weight(attn, "_ir_kv_cache", (tk, tv), dtype)
+            xs = src
+            if xs.dtype != dtype and not (FUSED_CAST and _own_gemm(xs, w, None)):
+                xs = xs.to(dtype)
+            kv = _linear(xs, w, None)
+            c = w.shape[0] // 2
+            return q, kv[..., :c], kv[..., c:], False, None
+        return q, tk(src), tv(src), False, None
     effs = [_lora.effective_linear(m) for m in (tq, tk, tv)]
     if any(e is None or e[0].bias is not None for e in effs) or \
             not (effs[0][0].weight.shape == effs[1][0].weight.shape == effs[2][0].weight.shape):
@@ -175,6 +191,22 @@ def _project_qkv(attn, st: _Prepared, want_stats: bool = False):
     if vstats is None:
         qkv = _ops.linear(x, w, None, **kw) if presc else _linear(x, w, None)
     return qkv[..., :c], qkv[..., c:2 * c], qkv[..., 2 * c:], presc, vstats
+
+
+def _project_single(attn, slot: str, bias_slot: str, module, x: torch.Tensor) -> torch.Tensor:
+    """one projection module (plain ``nn.Linear`` or a foldable LoRA wrapper in inference state) as one GEMM of this library
+    against its cached folded weight; the module call itself when it cannot be folded"""
+    eff = _lora.effective_linear(module)
+    if eff is None:
+        return module(x)
+    dtype = _autocast_or(eff[0].weight, x)
+    w = _lora.cached_weight(attn, slot, (module,), dtype)
+    bias = eff[0].bias
+    if bias is not None and bias.dtype != dtype:
+        bias = _lora.cached_cast(attn, bias_slot, bias, dtype)
+    if x.dtype != dtype and not (FUSED_CAST and _own_gemm(x, w, bias)):
+        x = x.to(dtype)
+    return _linear(x, w, bias)
 
 
 def _project_kv_only(attn, st: _Prepared):

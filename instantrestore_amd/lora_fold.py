@@ -120,7 +120,7 @@ def cached_cast(owner, slot: str, t: torch.Tensor, dtype) -> torch.Tensor:
     return cache[1]
 
 
-_SLOTS = ("_ir_qkv_cache", "_ir_out_cache", "_ir_out_bias_cache")
+_SLOTS = ("_ir_qkv_cache", "_ir_out_cache", "_ir_out_bias_cache", "_ir_q_cache", "_ir_q_bias_cache", "_ir_kv_cache")
 
 
 def invalidate(attn) -> None:

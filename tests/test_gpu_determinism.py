@@ -52,3 +52,8 @@ def test_no_vendor_gemm_in_the_step():
             for rows in (B * N * L, B * L):
                 assert ops.linear_kernel_for(rows, 3 * C, C, False) >= 1
                 assert ops.linear_kernel_for(rows, C, C, True) >= 1
+                # the f-1 cross-attention layers (round 4): q over the image tokens, k and v as ONE GEMM over the 77 text
+                # states of width 1024 (attn_processors._project_qkv)
+                assert ops.linear_kernel_for(rows, C, C, False) >= 1
+            for sets in (B * N, B):
+                assert ops.linear_kernel_for(sets * 77, 2 * C, 1024, False) >= 1

@@ -340,6 +340,35 @@ def test_full_size_layer_sampled_rows_and_properties(ops, L, H, N, dtype, inc):
     assert torch.equal(out, out2)
 
 
+def test_randomised_long_axis_sweep(ops):
+    """the 64-row kernel's territory (Lq >= 4096), which the small sweep never reaches: random ragged query / reference
+    lengths, 0-5 references, odd batch x head counts (item grids with and without a remainder split), both flags and dtypes;
+    sampled query rows against the fp32 CPU port on the full K/V.  IR_LONG_SWEEP_CASES / _SEED widen it for a soak."""
+    seed = int(os.environ.get("IR_LONG_SWEEP_SEED", "77"))
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator().manual_seed(seed)
+    for case in range(int(os.environ.get("IR_LONG_SWEEP_CASES", "4"))):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 6))
+        Lq = int(rng.choice([4096, 4096 + int(rng.integers(1, 600)), 8192 - int(rng.integers(0, 100))]))
+        N = int(rng.integers(0, 6))
+        Lr = int(rng.choice([Lq, int(rng.integers(64, 3000))])) if N else 0
+        inc = bool(rng.integers(0, 2)) or N == 0
+        ad = bool(rng.integers(0, 2)) and N > 0
+        dtype = [torch.float16, torch.bfloat16][case % 2]
+        C = H * 64
+        q, k = _rand((B, Lq, C), dtype, gen), _rand((B, Lq, C), dtype, gen)
+        v = _rand((B, Lq, C), dtype, gen, 0.9, 0.3)
+        rk = _rand((B, N, Lr, C), dtype, gen) if N else None
+        rv = _rand((B, N, Lr, C), dtype, gen, 1.4, -0.2) if N else None
+        c = lambda t: None if t is None else t.cuda()
+        aff = ops.adain_stats(c(v), c(rv), heads=H) if ad else None
+        out = ops.shared_attention(c(q), c(k), c(v), c(rk), c(rv), heads=H, scale=0.125, include_self=inc, adain=aff)
+        rows = torch.unique(torch.tensor([0, 31, 32, 63, 64, 511, 512, Lq // 2, Lq - 65, Lq - 1] + [int(r) for r in rng.integers(0, Lq, 6)]))
+        f = lambda t: None if t is None else t.float()
+        ref = O.shared_attention_port(q[:, rows].float(), f(k), f(v), f(rk), f(rv), H, 0.125, use_adain=ad, train_input=inc)
+        _check(out[:, rows], ref.numpy().astype(np.float64), dtype, f"long sweep case {case}: B{B} H{H} Lq{Lq} N{N} Lr{Lr} inc{inc} ad{ad}")
+
+
 def test_errors_are_loud(ops):
     q = torch.randn(1, 8, 64)
     with pytest.raises(RuntimeError):

@@ -19,3 +19,31 @@ def test_no_scratch_traffic_inside_the_gemm_main_loops(src):
                         os.path.join(ROOT, "instantrestore_amd", "csrc", src), "--fail", "linear"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_loop_scratch_detector_on_a_synthetic_listing():
+    """the guard's own logic, without a compiler: scratch inside an annotated MFMA loop is found, scratch in a cold block that
+    merely sits between the loop's labels in the layout - or in a loop without MFMAs - is not"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_loop_scratch as C
+    listing = """
+_Z3foov: ; @foo
+\tscratch_store_dword off, v1, off ; prologue spill: not in a loop
+.LBB0_1:                                ; =>This Inner Loop Header: Depth=1
+\tv_mfma_f32_32x32x16_bf16 v[0:15], v[16:19], v[20:23], v[0:15]
+\ts_cbranch_scc1 .LBB0_3
+.LBB0_2:                                ;   in Loop: Header=BB0_1 Depth=1
+\tscratch_load_dword v1, off, off ; 4-byte Folded Reload
+\ts_branch .LBB0_1
+.LBB0_3:
+\tscratch_load_dword v2, off, off ; cold block after the loop
+.LBB0_4:                                ; =>This Inner Loop Header: Depth=1
+\tscratch_load_dword v3, off, off ; a loop without MFMAs
+\ts_cbranch_scc1 .LBB0_4
+.Lfunc_end0:
+""".split("\n")
+    (name, s, e), = list(C.kernels(listing))
+    found = C.loops_with_scratch(listing, s, e)
+    assert name == "_Z3foov" and len(found) == 1
+    (_, label), (n_mfma, scr) = next(iter(found.items()))
+    assert label == ".LBB0_1" and n_mfma == 1 and len(scr) == 1 and "v1" in scr[0]

@@ -300,9 +300,10 @@ __global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKPa
   const int KT = p.K >> 6;
 
   // ---- tile walk: a workgroup takes tiles xs, xs + (workgroups on its XCD), ... of its XCD's contiguous range - exactly one
-  // when the launch has a workgroup per tile (the default), several when it is persistent (one workgroup per CU; then the
-  // next tile's first stage is in flight during the epilogue).  Measured equal: the ~6.5 us per tile beyond the K loop are
-  // the output write (HBM-bound burst), not launch or a cold first stage (profiles/r3_gemm_ablation.txt)
+  // when the launch has a workgroup per tile (tile counts up to the CU count), several when it is persistent (one workgroup per
+  // CU, the default for larger tile counts since round 4; then the next tile's first stage is in flight during the epilogue).
+  // The ~6.5 us per tile beyond the K loop are the output write (HBM-bound burst), not launch or a cold first stage
+  // (profiles/r3_gemm_ablation.txt); the persistent form hides a little of it: 1-3 % per multi-round GEMM (launch_pp)
   const int MT = (p.M + BM - 1) / BM, NTl = (p.N + BN - 1) / BN;   // the last column tile may be ragged (N % 64 == 0)
   const int ntiles = MT * NTl;
   const int xcd = blockIdx.x & 7, xs = blockIdx.x >> 3;
@@ -564,11 +565,13 @@ hipError_t launch_pp(const LinearKParams& p0, hipStream_t s) {
   }
   const int MT = (p.M + 255) / 256, NTl = (p.N + 255) / 256;
   const int ntiles = MT * NTl;
-  // One workgroup per tile by default: the hardware dispatcher then balances the tiles against whatever the other stream
-  // runs on the chip.  IR_LIN_PERSISTENT=1 (development A/B) launches one workgroup per CU that walks its share of the
-  // tiles with the next tile's first stage in flight during the epilogue - measured equal in isolation and in the step
-  // (profiles/r3_gemm_ablation.txt), and a late-starting persistent workgroup would hold its statically assigned tiles back.
-  static const bool persistent = getenv("IR_LIN_PERSISTENT") != nullptr;
+  // More tiles than CUs: ONE workgroup per CU walks its share of the tiles, with the next tile's first stage in flight during
+  // the epilogue (the epilogue is an HBM-write burst; a quarter of a K = 640 tile's life).  Round 3 measured this form equal to
+  // one workgroup per tile and kept the latter for the dispatcher's balancing; re-measured in round 4 on the short-K shapes of
+  // the step it is 1-3 % ahead per GEMM (tools/_r4_persist.sh: 102.2 -> 99.3, 33.8 -> 32.6 us) and 0.6-0.8 % on the whole
+  // two-stream step (7.019 -> 6.973 ms, three interleaved pairs), 0.2-0.6 % on one stream: the default since.
+  // IR_LIN_PERSISTENT=0 restores one workgroup per tile (A/B).
+  static const bool persistent = [] { const char* e = getenv("IR_LIN_PERSISTENT"); return e == nullptr || e[0] != '0'; }();
   const int grid = (persistent && ntiles > n_cu[dev]) ? n_cu[dev] : ntiles;
   hipLaunchKernelGGL((linear_tiled_pp_kernel<T, XF32>), dim3((unsigned)grid), dim3(512), dyn, s, p);
   return hipGetLastError();

@@ -539,10 +539,11 @@ __global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKPa
 // profiles/r4_gemm_halfstage.txt.  Not kept.)
 
 // row panels per walk group: every XCD owns a contiguous range of tiles ordered GM row panels x all column tiles, so the
-// ~32 tiles resident on an XCD form a GM x (32 / GM) patch.  8 x 4 is the measured optimum of the patch shapes tried
-// (profiles/r4_pmc_linear_tiled.txt); IR_LIN_GM overrides it for such measurements
+// ~32 tiles resident on an XCD form a GM x (32 / GM) patch.  Rounds 3-4 ran 8 x 4; 4 x 8 fetches 6 % less through the L2s
+// (profiles/r4_pmc_linear_tiled.txt), is ~1 % ahead per GEMM (r4_gemm_walk.txt) and 0.4 % on the two-stream step (6.809 ->
+// 6.783 ms, three interleaved triples with 2 / 4 / 8): the default since the end of round 4.  IR_LIN_GM overrides it (A/B)
 static int walk_group_rows() {
-  static const int gm = [] { const char* e = getenv("IR_LIN_GM"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 8; }();
+  static const int gm = [] { const char* e = getenv("IR_LIN_GM"); const int v = e ? atoi(e) : 0; return (v >= 1 && v <= 64) ? v : 4; }();
   return gm;
 }
 

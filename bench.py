@@ -145,7 +145,7 @@ def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached
         vals.append(p.values.reshape(-1, N, p.values.shape[1], p.values.shape[2]))
         if p.v_part is not None:    # round 4: content statistics as the capture GEMM's partials, merged by the shared layer's affine kernel
             from instantrestore_amd import ops as _o
-            stats.append(_o.RefStatsPartials(p.v_part, p.values.shape[0] // N, N, p.values.shape[1]))
+            stats.append(_o.RefStatsPartials(p.v_part, p.values.shape[0] // N, N, p.values.shape[1], producer=p.stream))
         else:
             stats.append(None if p.v_mean is None else (p.v_mean.reshape(-1, N, *p.v_mean.shape[-2:]), p.v_std.reshape(-1, N, *p.v_std.shape[-2:])))
         events.append(p.ready)
@@ -511,10 +511,26 @@ class CapturedStep:
         self.graph.replay()
 
 
-def determinism_report(layers, B, N, reps=10):
+def _first_difference(t, b):
+    """where two same-shape tensors first differ (row-major), how many elements do, and the two values there"""
+    ne = (t != b).flatten()
+    idx = int(ne.nonzero()[0])
+    where = []
+    rem = idx
+    for d in reversed(t.shape):
+        where.append(rem % d)
+        rem //= d
+    return {"elements": int(ne.sum()), "of": int(ne.numel()), "first_index": list(reversed(where)),
+            "got": float(t.flatten()[idx].float()), "expected": float(b.flatten()[idx].float()),
+            "max_abs": float((t.float() - b.float()).abs().max())}
+
+
+def determinism_report(layers, B, N, reps=10, modes=("one_stream", "two_streams", "hip_graph")):
     """The step run three ways - one stream, two streams, two streams replayed from one hipGraph - ``reps`` times each;
     every layer output and every harvested K/V tensor is compared bit for bit (``torch.equal``) with the first one-stream
-    run.  The reference runs one stream (inference/test.py:79-111), i.e. deterministically: so must every schedule here."""
+    run.  The reference runs one stream (inference/test.py:79-111), i.e. deterministically: so must every schedule here.
+    A mismatch is recorded with everything needed to bisect it: mode, repetition, tensor kind and layer (``out3`` / ``key7`` /
+    ``val0``), the layer's (L, C, H), how many elements differ, the first differing index with both values (``details``)."""
     def snap(res):
         outs, keys, vals = res
         return [t.clone() for t in list(outs) + list(keys) + list(vals)]
@@ -522,23 +538,28 @@ def determinism_report(layers, B, N, reps=10):
     names = ["out%d" % i for i in range(n)] + ["key%d" % i for i in range(n)] + ["val%d" % i for i in range(n)]
     base = snap(hot_path_step(layers, B, N, False, False, return_kv=True))
     torch.cuda.synchronize()
-    cap = CapturedStep(layers, B, N)
+    cap = CapturedStep(layers, B, N) if "hip_graph" in modes else None
     runs = {
         "one_stream": lambda: hot_path_step(layers, B, N, False, False, return_kv=True),
         "two_streams": lambda: hot_path_step(layers, B, N, False, True, return_kv=True),
         "hip_graph": lambda: (cap.replay(), (cap.outs, cap.keys, cap.vals))[1],
     }
     report = {}
-    for mode, fn in runs.items():
-        bad = {}
-        for _ in range(reps):
+    for mode in modes:
+        fn = runs[mode]
+        bad, details = {}, []
+        for rep in range(reps):
             got = fn()
             torch.cuda.synchronize()
-            for name, t, b in zip(names, list(got[0]) + list(got[1]) + list(got[2]), base):
+            for i, (name, t, b) in enumerate(zip(names, list(got[0]) + list(got[1]) + list(got[2]), base)):
                 if not torch.equal(t, b):
-                    bad[name] = max(bad.get(name, 0.0), float((t.float() - b.float()).abs().max()))
+                    d = _first_difference(t, b)
+                    bad[name] = max(bad.get(name, 0.0), d["max_abs"])
+                    if len(details) < 8:
+                        ly = layers[i % n]
+                        details.append(dict(d, mode=mode, repetition=rep, tensor=name, layer=i % n, L=ly["L"], C=ly["C"], H=ly["H"]))
             del got
-        report[mode] = {"runs": reps, "identical": not bad, "mismatching": bad}
+        report[mode] = {"runs": reps, "identical": not bad, "mismatching": bad, "details": details}
     del cap
     return report
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IR_ABI_VERSION 7
+#define IR_ABI_VERSION 8
 #define IR_HEAD_DIM 64
 
 typedef enum ir_status {
@@ -111,6 +111,12 @@ typedef struct ir_shared_attn_args {
   int32_t tuning;           /* 0 = default kernel dispatch.  Benchmarks / A-B tests only: IR_TUNE_* selects one kernel
                                for this call (an unknown or unavailable value is IR_ERR_UNSUPPORTED). */
   int32_t reserved;         /* must be 0 */
+  const int32_t* valid_refs; /* ABI v8, optional: int32 (B) on the device.  References n >= valid_refs[b] of batch entry b are
+                               ALL-ZERO in k_ref and v_ref (ir_zero_invalid_refs; pix2pix_turbo.py:269-273) - a promise by the
+                               caller, which lets the kernel account for those segments in closed form (every score of a zero
+                               key is exactly 0, every value row is 0, or the AdaIN shift b when an affine is given) instead of
+                               walking their tiles.  Same result as with NULL: zeroed, not masked - the tokens keep their exp(0)
+                               weight.  NULL = every reference is walked. */
 } ir_shared_attn_args;
 
 /* values of ir_shared_attn_args.tuning (csrc/shared_attn_fwd.hip lists what each one is) */
@@ -149,8 +155,28 @@ int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream);
  * Uses the same args as ir_shared_attn_fwd (out / adain_* are ignored) plus the `lse` that
  * call produced:  probs[b,h,i,j] = exp(scale*<q_i,k_j> - lse[b,h,i]), stored in `dtype`,
  * contiguous, column order as above.
+ *
+ * HBM-write bound (H*L*Lkv*2 bytes per identity).  When len_self and len_ref are multiples of 8 keys (every row of
+ * probs then starts 16-byte aligned) the line kernel runs: whole 128-byte lines per store instruction (round 5); other
+ * lengths take the 2-byte-store kernel.  ir_attn_probs_ex names the kernel (benchmarks / A-B tests).
  */
 int ir_attn_probs(const ir_shared_attn_args* args, void* probs, void* stream);
+#define IR_PROBS_AUTO 0
+#define IR_PROBS_GENERIC 1   /* 2-byte stores, any length */
+#define IR_PROBS_LINES64 2   /* line kernel, 64 query rows per wave */
+#define IR_PROBS_LINES32 3   /* line kernel, 32 query rows per wave */
+int ir_attn_probs_ex(const ir_shared_attn_args* args, void* probs, int32_t kernel, void* stream);
+
+/*
+ * ir_attn_segment_mass (ABI v8, opt-in) - attention mass per K/V segment without the probability matrix.
+ *
+ *   mass[b,h,i,s] = sum over the keys j of segment s of exp(scale*<q_i,k_j> - lse[b,h,i]),  fp32 (B, H, len_q, S) contiguous,
+ *   segments s in the column order above: [self (iff IR_FLAG_INCLUDE_SELF)] ++ ref 0 ++ ... ++ ref N-1, S = include_self + N.
+ * What gradio_demo.py:119-127 reduces attention_probs to (`probs[..., attn_size*idx : attn_size*(idx+1)].sum(-1)` per
+ * reference): the same numbers (summed in fp32 before any 16-bit rounding) without writing H*L*Lkv*2 bytes.  Same args as
+ * ir_attn_probs; any segment length.
+ */
+int ir_attn_segment_mass(const ir_shared_attn_args* args, float* mass, void* stream);
 
 /*
  * ir_adain_stats - per-(b, n, channel) AdaIN affine from token statistics.

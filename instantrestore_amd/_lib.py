@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # IR_LIB_PATH: load an alternative build of the same ABI (compiler-flag A/B experiments)
 LIB_PATH = os.environ.get("IR_LIB_PATH") or os.path.join(_HERE, "libinstantrestore_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 IR_DTYPE_F16, IR_DTYPE_BF16 = 0, 1
 IR_FLAG_INCLUDE_SELF, IR_FLAG_Q_PRESCALED, IR_FLAG_OUT_F32 = 1, 2, 4
@@ -31,7 +31,7 @@ class SharedAttnArgs(C.Structure):
         + [(n, i64) for n in ("q_sb", "q_sl", "q_sh", "ks_sb", "ks_sl", "ks_sh", "vs_sb", "vs_sl", "vs_sh",
                               "kr_sb", "kr_sn", "kr_sl", "kr_sh", "vr_sb", "vr_sn", "vr_sl", "vr_sh",
                               "o_sb", "o_sl", "o_sh")]
-        + [("workspace", vp), ("workspace_bytes", C.c_uint64), ("tuning", i32), ("reserved", i32)]
+        + [("workspace", vp), ("workspace_bytes", C.c_uint64), ("tuning", i32), ("reserved", i32), ("valid_refs", vp)]
     )
 
 
@@ -56,6 +56,8 @@ SYMBOLS = {
     "ir_bench_mfma_stream_scratch_bytes": (C.c_size_t, []),
     "ir_bench_mfma_stream": (C.c_int, [i32, i32, i32, i32, vp, C.c_size_t, vp, C.POINTER(f32)]),
     "ir_attn_probs": (C.c_int, [C.POINTER(SharedAttnArgs), vp, vp]),
+    "ir_attn_probs_ex": (C.c_int, [C.POINTER(SharedAttnArgs), vp, i32, vp]),
+    "ir_attn_segment_mass": (C.c_int, [C.POINTER(SharedAttnArgs), vp, vp]),
     "ir_adain_stats_workspace_bytes": (C.c_size_t, [i32, i32, i32, i32, i32]),
     "ir_adain_stats": (C.c_int, [i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, vp, i64, i64, i64, i64,
                                  f32, vp, vp, vp, C.c_size_t, vp]),

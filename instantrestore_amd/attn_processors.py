@@ -396,7 +396,10 @@ class SharedAttnProcessor(nn.Module):
                 ref_keys=None, ref_values=None, ref_events=None, ref_stats=None):
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         shared = self.self_attn_idx is not None and ref_keys is not None and ref_values is not None
-        query, key, value, presc, vstats = _project_qkv(attn, st, want_stats=bool(shared and self.use_adain))
+        # the GEMM's statistics tail (style partials of this layer's own V) only pays when the content statistics arrive
+        # precomputed (``ref_stats``): without them ir_adain_stats reads every V anyway and would throw the partials away
+        have_cstats = bool(shared and ref_stats is not None and ref_stats[self.self_attn_idx] is not None)
+        query, key, value, presc, vstats = _project_qkv(attn, st, want_stats=bool(self.use_adain and have_cstats))
 
         ref_k = ref_v = None
         include_self = True
@@ -417,6 +420,8 @@ class SharedAttnProcessor(nn.Module):
                 elif cstats is not None:
                     cstats[0].record_stream(cur)
                     cstats[1].record_stream(cur)
+            elif hasattr(cstats, "sync_to_current"):
+                cstats.sync_to_current()      # no event handed over: order this stream behind the partials' producer (no-op on one stream)
             include_self = bool(self.train_input)
             if self.use_adain:
                 # style = this image's own post-projection V; content = each reference V.  With the content statistics

@@ -15,6 +15,18 @@ constexpr int ROWS = IR_ADAIN_ROWS;  // token rows per workgroup
 constexpr int AT = 256;              // threads: 32 row slots x 8 sixteen-byte column slots
 
 // Chan et al. merge of (n, mean, M2) partials.
+// a = (sigma_v + eps) / (sigma_x + eps) (attn_processors.py:10,16,245) - except where the content std is EXACTLY 0 (M2 == 0:
+// every token of the reference channel holds one value; a zero-filled reference, pix2pix_turbo.py:269-273, or a short token
+// axis whose values round to the same 16-bit number).  There x - mean(x) is exactly 0 and the reference's adain() returns the
+// style mean whatever the ratio, while the affine form a*x + b with a = sigma_v / 1e-5 ~ 1e5 has to cancel a*x against
+// -a*mean(x) in fp32 (round-4 soak): the fused result lost the style mean.  Any small ratio gives the same
+// function on such a channel; the ideal is a = 0 (what oracle.adain_affine_np reports), but the 64-row attention kernel's
+// ratio frame divides by a, so the kernels emit a = 2^-24 (sigma_v + eps): b = mean(V_self) - mean(x) * a then differs from
+// the style mean by < 6e-8 |x| sigma_v, and a*x + b from it by the fp32 rounding of that.
+__device__ __forceinline__ float adain_scale(float sd_v_eps, float sd_x_eps, bool content_is_constant) {
+  return content_is_constant ? sd_v_eps * 5.9604644775390625e-8f : sd_v_eps / sd_x_eps;
+}
+
 __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
   if (nb == 0.f) return;
   const float nt = n + nb;
@@ -130,7 +142,7 @@ __global__ void __launch_bounds__(64) adain_finalize_kernel(const AdainKParams p
   // torch.std default: unbiased (n-1); a single token gives 0/0 = NaN exactly like torch
   const float sd_v = sqrtf(m2_v / (float)(p.Ls - 1)) + p.eps;
   const float sd_x = sqrtf(m2_x / (float)(p.Lr - 1)) + p.eps;
-  const float a = sd_v / sd_x;
+  const float a = adain_scale(sd_v, sd_x, m2_x == 0.f);
   const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
   p.a[o] = a;
   p.b[o] = mu_v - mu_x * a;
@@ -167,7 +179,7 @@ __global__ void __launch_bounds__(256) adain_finalize_staged_kernel(const AdainK
     const int n = i >> 6, d = i & 63;
     const float sd_v = sqrtf(stats[64 + d] / (float)(p.Ls - 1)) + p.eps;
     const float sd_x = sqrtf(stats[(1 + n) * 128 + 64 + d] / (float)(p.Lr - 1)) + p.eps;
-    const float a = sd_v / sd_x;
+    const float a = adain_scale(sd_v, sd_x, stats[(1 + n) * 128 + 64 + d] == 0.f);
     const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
     p.a[o] = a;
     p.b[o] = stats[d] - stats[(1 + n) * 128 + d] * a;
@@ -206,7 +218,7 @@ __global__ void __launch_bounds__(256) adain_finalize_cached_kernel(const AdainK
     const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
     const float sd_v = sqrtf(stats[64 + d] / (float)(p.Ls - 1)) + p.eps;
     const float sd_x = p.cstd[o] + p.eps;     // cstd = sqrtf(M2_x / (Lr - 1)): the expression of the uncached kernels
-    const float a = sd_v / sd_x;
+    const float a = adain_scale(sd_v, sd_x, p.cstd[o] == 0.f);
     p.a[o] = a;
     p.b[o] = stats[d] - p.cmean[o] * a;
   }
@@ -227,7 +239,7 @@ __global__ void __launch_bounds__(64) adain_finalize_cached_direct_kernel(const 
   const float sd_v = sqrtf(m2 / (float)(p.Ls - 1)) + p.eps;
   for (int n = 0; n < p.N; ++n) {
     const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
-    const float a = sd_v / (p.cstd[o] + p.eps);
+    const float a = adain_scale(sd_v, p.cstd[o] + p.eps, p.cstd[o] == 0.f);
     p.a[o] = a;
     p.b[o] = mean - p.cmean[o] * a;
   }
@@ -296,7 +308,7 @@ __global__ void __launch_bounds__(AT) adain_self_small_kernel(const AdainKParams
     const int64_t o = (((int64_t)b * p.N + n) * p.H + h) * 64 + d;
     const float sd_v = sqrtf(stats[64 + d] / (float)(p.Ls - 1)) + p.eps;
     const float sd_x = p.cstd[o] + p.eps;
-    const float a = sd_v / sd_x;
+    const float a = adain_scale(sd_v, sd_x, p.cstd[o] == 0.f);
     p.a[o] = a;
     p.b[o] = stats[d] - p.cmean[o] * a;
   }
@@ -558,7 +570,7 @@ __global__ void __launch_bounds__(1024) adain_affine_partials_kernel(const Adain
     else if (merge_c) { mu_x = mean_c; sd_x = sqrtf(sum16(red[3], d) / (float)(p.Lr - 1)); }
     else { mu_x = p.cmean[o]; sd_x = p.cstd[o]; }
     const float sd_v = sqrtf(sum16(red[2], d) / (float)(p.Ls - 1)) + p.eps;
-    const float a = sd_v / (sd_x + p.eps);
+    const float a = adain_scale(sd_v, sd_x + p.eps, sd_x == 0.f);
     p.a[o] = a;
     p.b[o] = mean_s - mu_x * a;
   }

@@ -190,14 +190,29 @@ int ir_bench_mfma_stream(int32_t dtype, int32_t zero_operands, int32_t iters, in
   return IR_OK;
 }
 
-int ir_attn_probs(const ir_shared_attn_args* args, void* probs, void* stream) {
+int ir_attn_probs_ex(const ir_shared_attn_args* args, void* probs, int32_t kernel, void* stream) {
   AttnKParams p;
   const int rc = build_attn_params(args, &p, false);
   if (rc != IR_OK) return rc;
   if (probs == nullptr || args->lse == nullptr) return fail(IR_ERR_INVALID_ARG, "probs/lse is NULL");
+  if (kernel < IR_PROBS_AUTO || kernel > IR_PROBS_LINES32) return fail(IR_ERR_UNSUPPORTED, "attn_probs kernel %d", kernel);
   p.probs = probs;
-  const hipError_t e = ir_launch_attn_probs(p, args->dtype, (hipStream_t)stream);
+  if (kernel >= IR_PROBS_LINES64 && !ir_attn_probs_uses_lines(p))
+    return fail(IR_ERR_UNSUPPORTED, "the line kernel needs len_self, len_ref (and so Lkv) to be multiples of 8 and probs 16-byte aligned");
+  const hipError_t e = ir_launch_attn_probs(p, args->dtype, kernel, (hipStream_t)stream);
   if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "attn_probs launch: %s", hipGetErrorString(e));
+  return IR_OK;
+}
+
+int ir_attn_probs(const ir_shared_attn_args* args, void* probs, void* stream) { return ir_attn_probs_ex(args, probs, IR_PROBS_AUTO, stream); }
+
+int ir_attn_segment_mass(const ir_shared_attn_args* args, float* mass, void* stream) {
+  AttnKParams p;
+  const int rc = build_attn_params(args, &p, false);
+  if (rc != IR_OK) return rc;
+  if (mass == nullptr || args->lse == nullptr) return fail(IR_ERR_INVALID_ARG, "mass/lse is NULL");
+  const hipError_t e = ir_launch_attn_segment_mass(p, args->dtype, mass, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "attn_segment_mass launch: %s", hipGetErrorString(e));
   return IR_OK;
 }
 
@@ -558,6 +573,10 @@ static int linear_fwd_impl(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n
     if (rows <= 0 || (m % rows) != 0) return fail(IR_ERR_UNSUPPORTED, "statistics tail: M = %lld is not a multiple of the kernel's %d-row blocks (ir_linear_stats_rows)", (long long)m, rows);
     const size_t need = (size_t)(m / rows) * (size_t)(st_cols / 64) * 128 * sizeof(float);
     if (st_ws_bytes < need) return fail(IR_ERR_WORKSPACE, "stats_ws %zu < %zu bytes", st_ws_bytes, need);
+    // the K = 640 X-stationary kernel re-reads the rows it has just stored (ir_wave_col_stats): every 128-byte line of the
+    // statistics columns must belong to ONE workgroup's column range, i.e. rows of y start on a line and so does column st_col0
+    if (kernel == IR_LIN_X_STATIONARY && k == 640 && (((y_ld * 2) % 128) != 0 || (((uintptr_t)y + (uintptr_t)st_col0 * 2) % 128) != 0))
+      return fail(IR_ERR_UNSUPPORTED, "statistics tail at K = 640: y + stats_col0 must be 128-byte aligned and y_ld a multiple of 64 elements");
     p.st_ws = st_ws; p.st_col0 = st_col0; p.st_cols = st_cols;
   }
   const hipError_t e =

@@ -101,7 +101,10 @@ static __device__ __forceinline__ void ir_wave_col_stats(const T* __restrict__ y
     for (int hb = 0; hb < HB; ++hb) {
       const int head = (h0 + hb) < head_hi ? (h0 + hb) : (head_hi - 1);    // past the range: the last head again (not stored)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xs[hb][j] = *(const u32x4*)(base + head * 64 + (int64_t)(rs + 8 * j) * y_ld);
+      // nt: served by the L2 this wave's stores went to, never by the CU's vector L1.  A plain load could hit a line another
+      // wave of this CU pulled into L1 BEFORE the stores (only possible when y's 128-B lines straddle the column ranges of
+      // two workgroups - the C ABI now refuses that for a statistics call - but the tail must not depend on it)
+      for (int j = 0; j < 8; ++j) xs[hb][j] = __builtin_nontemporal_load((const u32x4*)(base + head * 64 + (int64_t)(rs + 8 * j) * y_ld));
     }
 #pragma unroll
     for (int hb = 0; hb < HB; ++hb) {

@@ -114,7 +114,11 @@ static inline int ir_pick_split(int rem, int slots, int kmax, long cap_pieces) {
   return best_k;
 }   // the default dispatch rule (variant 0)
 hipError_t ir_launch_shared_attn_fwd_pp(const AttnKParams& p, int dtype, hipStream_t s);
-hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, hipStream_t s);
+// variant: 0 = automatic (line kernel when every segment length is a multiple of 8), 1 = round 1's 2-byte-store kernel,
+// 2 / 3 = the line kernel with 64 / 32 query rows per wave
+hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, int variant, hipStream_t s);
+bool ir_attn_probs_uses_lines(const AttnKParams& p);
+hipError_t ir_launch_attn_segment_mass(const AttnKParams& p, int dtype, float* mass, hipStream_t s);
 hipError_t ir_launch_adain_stats(const AdainKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_token_stats(const AdainKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_adain_stats_cached(const AdainKParams& p, int dtype, hipStream_t s);

@@ -50,7 +50,7 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
         if with_stats and getattr(p, "v_part", None) is not None:
             # round 4: the capture layer's q/k/v GEMM left the partial statistics of its V third behind; they travel as they
             # are (the shared layer's affine kernel merges them), with the valid counts when references get zero-filled below
-            stats.append(_ops.RefStatsPartials(p.v_part, v.shape[0], n_refs, v.shape[2]))
+            stats.append(_ops.RefStatsPartials(p.v_part, v.shape[0], n_refs, v.shape[2], producer=streams[-1]))
         elif with_stats:
             m, sd = getattr(p, "v_mean", None), getattr(p, "v_std", None)
             if m is None and v.is_cuda:      # not stashed at capture time: one pass over V now, behind its producer

@@ -256,21 +256,39 @@ def shared_attention_kernel_name(q, k_self, v_self, ref_k=None, ref_v=None, *, h
     return _lib.lib().ir_shared_attn_kernel_name(C.byref(args)).decode()
 
 
-@_on_tensor_device
-def attn_probs(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True) -> torch.Tensor:
-    """Materialise ``attention_probs`` (B, H, Lq, Lkv) from the LSE of the fused forward
-    (``ir_attn_probs``; the ``save_self_attentions`` dump path, attn_processors.py:258-261)."""
-    v_dummy = k_self
-    r_dummy = ref_k
-    q, k_self, _, ref_k, _ = _prep(q, k_self, v_dummy, ref_k, r_dummy, heads, include_self, None)
+PROBS_KERNELS = {"auto": 0, "generic": 1, "lines64": 2, "lines32": 3}   # IR_PROBS_*
+
+
+def _probs_args(q, k_self, ref_k, lse, heads, scale, include_self):
+    q, k_self, _, ref_k, _ = _prep(q, k_self, k_self, ref_k, ref_k, heads, include_self, None)
     B, Lq, _ = q.shape
     lkv = (k_self.shape[1] if include_self else 0) + (ref_k.shape[1] * ref_k.shape[2] if ref_k is not None else 0)
     if lse.dtype != torch.float32 or not lse.is_contiguous() or tuple(lse.shape) != (B, heads, Lq):
         raise ValueError("lse must be contiguous fp32 (B, H, Lq)")
-    probs = torch.empty((B, heads, Lq, lkv), dtype=q.dtype, device=q.device)
     args = _fill_args(q, k_self, k_self, ref_k, ref_k, heads, scale, include_self, None, None, lse)
-    _lib.check(_lib.lib().ir_attn_probs(C.byref(args), probs.data_ptr(), _stream()), "ir_attn_probs")
+    return args, q, B, Lq, lkv, (q, k_self, ref_k, lse)
+
+
+@_on_tensor_device
+def attn_probs(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True, kernel: str = "auto") -> torch.Tensor:
+    """Materialise ``attention_probs`` (B, H, Lq, Lkv) from the LSE of the fused forward
+    (``ir_attn_probs``; the ``save_self_attentions`` dump path, attn_processors.py:258-261).
+    ``kernel``: ``PROBS_KERNELS`` (benchmarks / A-B tests; "auto" is what the processors use)."""
+    args, q, B, Lq, lkv, _keep = _probs_args(q, k_self, ref_k, lse, heads, scale, include_self)
+    probs = torch.empty((B, heads, Lq, lkv), dtype=q.dtype, device=q.device)
+    _lib.check(_lib.lib().ir_attn_probs_ex(C.byref(args), probs.data_ptr(), PROBS_KERNELS[kernel], _stream()), "ir_attn_probs")
     return probs
+
+
+@_on_tensor_device
+def attn_segment_mass(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True) -> torch.Tensor:
+    """Attention mass per K/V segment, fp32 (B, H, Lq, include_self + N), without the probability matrix
+    (``ir_attn_segment_mass``): what gradio_demo.py:119-127 reduces ``attention_probs`` to."""
+    args, q, B, Lq, _, _keep = _probs_args(q, k_self, ref_k, lse, heads, scale, include_self)
+    nseg = (1 if include_self else 0) + (ref_k.shape[1] if ref_k is not None else 0)
+    mass = torch.empty((B, heads, Lq, nseg), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.lib().ir_attn_segment_mass(C.byref(args), mass.data_ptr(), _stream()), "ir_attn_segment_mass")
+    return mass
 
 
 @_on_tensor_device
@@ -451,23 +469,48 @@ class RefStatsPartials:
     the ``(mean, std)`` pair of ``(B, N, H, 64)`` tensors that a per-identity cache stores.  ``valid``: int32 ``(B,)`` device
     tensor when references ``n >= valid[b]`` were zero-filled by the harvest (statistics (0, 0)), else ``None``."""
 
-    __slots__ = ("part", "batch", "n_refs", "length", "valid")
+    __slots__ = ("part", "batch", "n_refs", "length", "valid", "producer", "_finished")
 
-    def __init__(self, part: ColumnStats, batch: int, n_refs: int, length: int, valid: Optional[torch.Tensor] = None):
+    def __init__(self, part: ColumnStats, batch: int, n_refs: int, length: int, valid: Optional[torch.Tensor] = None,
+                 producer: Optional["torch.cuda.Stream"] = None):
+        """``producer``: the HIP stream the capture layer's GEMM wrote the partials on (``AttnProcessor.stream``); a merge
+        launched on another stream first waits for everything enqueued there (``finished()`` on the main stream
+        could read the partials before the capture stream's GEMM tail had written them when no event was handed over)."""
         self.part, self.batch, self.n_refs, self.length, self.valid = part, int(batch), int(n_refs), int(length), valid
+        self.producer = producer
+        self._finished = None
+
+    def __setattr__(self, name, value):
+        if name == "valid":     # the zero fill changes which references count as all-zero: a cached merge is stale
+            object.__setattr__(self, "_finished", None)
+        object.__setattr__(self, name, value)
 
     def record_stream(self, stream) -> None:
         self.part.ws.record_stream(stream)
         if self.valid is not None:
             self.valid.record_stream(stream)
 
+    def sync_to_current(self) -> None:
+        """order the current stream behind the partials' producer (no-op on the producer's own stream)"""
+        if self.producer is None or not self.part.ws.is_cuda:
+            return
+        cur = torch.cuda.current_stream(self.part.ws.device)
+        if cur != self.producer:
+            cur.wait_stream(self.producer)
+            self.record_stream(cur)
+
     def finished(self):
+        """``(mean, std)`` of every reference V, fp32 ``(B, N, H, 64)``: merged once, then cached on the object"""
+        if self._finished is not None:
+            return self._finished
+        self.sync_to_current()
         mean, std = token_stats_from_partials(self.part, self.batch * self.n_refs, self.length)
         mean, std = mean.reshape(self.batch, self.n_refs, *mean.shape[-2:]), std.reshape(self.batch, self.n_refs, *std.shape[-2:])
         if self.valid is not None:
             keep = (torch.arange(self.n_refs, device=mean.device)[None, :] < self.valid.reshape(-1, 1)).to(torch.float32)[:, :, None, None]
             mean, std = mean * keep, std * keep
-        return mean.contiguous(), std.contiguous()
+        self._finished = (mean.contiguous(), std.contiguous())
+        return self._finished
 
 
 @_on_tensor_device

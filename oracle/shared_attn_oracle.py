@@ -78,6 +78,10 @@ def adain_affine_np(v_self: np.ndarray, ref_v: np.ndarray, heads: int):
         mu_x, sd_x = token_stats_np(ref_v[:, n])
         with np.errstate(invalid="ignore", divide="ignore"):
             a_n = (sd_v + ADAIN_EPS) / (sd_x + ADAIN_EPS)
+        # content std exactly 0 (a zero-filled reference, pix2pix_turbo.py:269-273, or a constant channel): every token equals
+        # the mean, adain_np() above returns exactly style_mean for ANY ratio - the affine that says so without a 1e5 * x
+        # against -1e5 * mean cancellation is (0, mu_v).  adain_np(x) == x * a + b holds either way (tests/test_oracle_golden.py).
+        a_n = np.where(sd_x == 0, 0.0, a_n)
         a[:, n] = a_n[:, 0]
         b[:, n] = (mu_v - mu_x * a_n)[:, 0]
     return a, b

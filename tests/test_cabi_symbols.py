@@ -48,7 +48,7 @@ def test_struct_mirror_matches_header_field_order():
         else:
             fields.append(names.lstrip("*"))
     assert fields == [f[0] for f in _lib.SharedAttnArgs._fields_]
-    assert C.sizeof(_lib.SharedAttnArgs) == 10 * 4 + 9 * 8 + 20 * 8 + 16 + 8
+    assert C.sizeof(_lib.SharedAttnArgs) == 10 * 4 + 9 * 8 + 20 * 8 + 16 + 8 + 8   # + valid_refs (ABI v8)
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():

@@ -464,11 +464,10 @@ def test_randomised_shape_sweep(ops):
         N = int(rng.integers(0, 10))
         Lr = int(rng.integers(2, max_lr)) if N else 0
         inc = bool(rng.integers(0, 2)) or N == 0
-        # AdaIN needs a content std that is not ~0: with 2-7 reference tokens a channel whose tokens round to the same 16-bit value
-        # has std 0, a = std(V_self) / eps ~ 1e5, and the fused affine a*v + b cancels catastrophically where the reference's
-        # (v - mean) / std * ... is exactly 0 (found by the round-4 soak: Lr = 2).  Zero-FILLED references are exact
-        # (tests/test_gpu_adain_cached.py); real token axes have >= 64 tokens.
-        ad = bool(rng.integers(0, 2)) and N > 0 and Lq > 1 and Lr >= 8
+        # AdaIN on short reference axes (round 5): a channel whose 2-7 tokens round to the SAME 16-bit value has content std exactly
+        # 0; the affine kernels emit (a, b) = (0, mean(V_self)) there - what the reference's (v - mean) / (std + eps) * s + m gives -
+        # instead of a = std(V_self) / 1e-5 (round-4 soak: the fused a*v + b cancelled catastrophically).
+        ad = bool(rng.integers(0, 2)) and N > 0 and Lq > 1 and Lr >= 2
         dtype = [torch.float16, torch.bfloat16][case % 2]
         C = H * 64
         q, k, v = (_rand((B, Lq, C), dtype, gen, 1.3) for _ in range(3))
@@ -552,6 +551,38 @@ def test_training_mode_is_refused_loudly(ops):
         ops.shared_attention(q, q, q, heads=1, scale=0.125)
     with pytest.raises(NotImplementedError, match="forward-only"):
         ops.linear(q.reshape(64, 64), torch.zeros(32, 64, device="cuda", dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("variant", [0, 10, 13], ids=["default", "pipe32", "w64x8"])
+@pytest.mark.parametrize("L,Lr", [(320, 320), (70, 2), (4096, 64)], ids=["L320", "Lr2", "L4096"])
+def test_constant_reference_channels_get_the_style_mean(ops, dtype, variant, L, Lr):
+    """a reference channel whose tokens all hold ONE non-zero value (content std exactly 0, mean not): the reference's
+    (x - mean) / (0 + eps) * s + m is exactly the style mean; the fused a*x + b of rounds 1-4 (a = s / 1e-5) lost it to fp32
+    cancellation (round-4 soak at Lr = 2).  Round 5: the affine kernels emit a negligible ratio there."""
+    g = torch.Generator().manual_seed(23 + L)
+    B, H, N = 1, 2, 3
+    C = H * 64
+    q, k, v = (torch.randn(B, L, C, generator=g) for _ in range(3))
+    rk, rv = torch.randn(B, N, Lr, C, generator=g), torch.randn(B, N, Lr, C, generator=g) * 0.9 + 0.4
+    rv[:, 0, :, 7] = 0.4375          # one constant channel
+    rv[:, 2, :, 64:] = -1.25         # a whole head constant
+    rv[:, 1, :, 3] = 3.0
+    q, k, v, rk, rv = (t.to(dtype) for t in (q, k, v, rk, rv))
+    ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.125, True, True)
+    c = lambda t: t.cuda()
+    a_ref, b_ref = O.adain_affine_np(_np64(v), _np64(rv), H)
+    ops.set_attn_variant(variant)
+    try:
+        aff = ops.adain_stats(c(v), c(rv), heads=H)
+        out = ops.shared_attention(c(q), c(k), c(v), c(rk), c(rv), heads=H, scale=0.125, include_self=True, adain=aff)
+    finally:
+        ops.set_attn_variant(0)
+    a, b = aff[0].cpu().numpy().reshape(B, N, C), aff[1].cpu().numpy().reshape(B, N, C)
+    const = a_ref == 0
+    assert const.sum() == 1 + 64 + 1
+    assert np.abs(a[const]).max() <= 1e-6 and np.abs(b[const] - b_ref[const]).max() <= 1e-5
+    _check(out, ref, dtype, "constant reference channels")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])

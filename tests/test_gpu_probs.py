@@ -1,0 +1,155 @@
+"""The dump path on the GPU (attn_processors.py:258-261): every kernel of ``ir_attn_probs_ex`` and the opt-in per-segment mass
+(``ir_attn_segment_mass``) against the float64 oracle's probability matrix on identical 16-bit-rounded inputs.
+
+Tolerance (floating point): probabilities are in [0, 1], so the bound of tests/test_gpu_parity.py reads
+``max|P - P_ref| <= TOL[dtype]`` (1e-3 fp16, 8e-3 bf16: one ulp of the 16-bit output at 1.0); rows sum to 1 within 4x that.
+The kernels of one call are also compared with each other BIT FOR BIT: they evaluate the same expression
+(exp2(fma(s, scale*log2e, -lse*log2e)) on the fp32 MFMA result), only the store shape differs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import shared_attn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from instantrestore_amd import ops as _ops
+    _ops._lib.lib()
+    return _ops
+
+
+def _rand(shape, dtype, gen, scale=1.0):
+    return (torch.randn(shape, generator=gen) * scale).to(dtype)
+
+
+def _np64(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+CASES = [
+    # B, H, Lq, Ls, N, Lr, include_self        (line kernel needs Ls, Lr multiples of 8)
+    (2, 2, 72, 72, 3, 40, True),       # ragged 64-key steps, partial row block
+    (2, 2, 72, 72, 3, 40, False),
+    (1, 3, 256, 256, 4, 256, True),    # the 16x16-token class, thin
+    (1, 2, 300, 304, 2, 136, True),    # rows not a multiple of 32, key tails of 8 / 48 keys
+    (1, 1, 520, 520, 1, 1032, False),  # more than one 256-row workgroup, a reference longer than the query axis
+    (2, 1, 64, 64, 8, 64, True),       # eight references
+    (1, 2, 96, 96, 0, 0, True),        # no references: plain self attention
+    (1, 1, 1024, 1024, 4, 1024, True), # the 32x32-token class, one head: key chunks cut the segments
+]
+ODD_CASES = [
+    (2, 2, 33, 33, 2, 37, True),       # nothing aligned: rows of P start at odd byte offsets -> generic kernel
+    (1, 2, 64, 64, 3, 20, False),      # Lr % 8 != 0
+    (1, 1, 77, 77, 1, 1, True),
+]
+
+
+def _case_inputs(case, dtype, seed=5):
+    B, H, Lq, Ls, N, Lr, inc = case
+    C = H * 64
+    gen = torch.Generator().manual_seed(seed)
+    q = _rand((B, Lq, C), dtype, gen, 1.5)
+    k, v = _rand((B, Ls, C), dtype, gen, 1.5), _rand((B, Ls, C), dtype, gen)
+    rk = _rand((B, N, Lr, C), dtype, gen, 1.5) if N else None
+    rv = _rand((B, N, Lr, C), dtype, gen) if N else None
+    return q, k, v, rk, rv
+
+
+def _oracle_probs(q, k, v, rk, rv, H, inc):
+    n = lambda t: None if t is None else _np64(t)
+    _, p = O.shared_attention_np(_np64(q), _np64(k), _np64(v), n(rk), n(rv), H, 0.125, False, inc, return_probs=True)
+    return p
+
+
+def _gpu_lse(ops, q, k, v, rk, rv, H, inc):
+    d = lambda t: None if t is None else t.cuda()
+    qd, kd, vd, rkd, rvd = d(q), d(k), d(v), d(rk), d(rv)
+    _, lse = ops.shared_attention(qd, kd, vd, rkd, rvd, heads=H, scale=0.125, include_self=inc, return_lse=True)
+    return qd, kd, rkd, lse
+
+
+def _ids(cases):
+    return [f"B{c[0]}H{c[1]}L{c[2]}Ls{c[3]}N{c[4]}Lr{c[5]}s{int(c[6])}" for c in cases]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=_ids(CASES))
+def test_every_probs_kernel_against_the_oracle(ops, case, dtype):
+    B, H, Lq, Ls, N, Lr, inc = case
+    q, k, v, rk, rv = _case_inputs(case, dtype)
+    p_ref = _oracle_probs(q, k, v, rk, rv, H, inc)
+    qd, kd, rkd, lse = _gpu_lse(ops, q, k, v, rk, rv, H, inc)
+    got = {}
+    for kern in ("auto", "generic", "lines64", "lines32"):
+        probs = ops.attn_probs(qd, kd, rkd, lse, heads=H, scale=0.125, include_self=inc, kernel=kern)
+        assert probs.shape == p_ref.shape and probs.dtype == dtype
+        p = probs.float().cpu().numpy()
+        assert np.isfinite(p).all(), kern
+        assert np.abs(p - p_ref).max() <= TOL[dtype], (kern, np.abs(p - p_ref).max())
+        np.testing.assert_allclose(p.sum(-1), 1.0, atol=4 * TOL[dtype])
+        got[kern] = probs
+    for kern in ("auto", "lines64", "lines32"):
+        assert torch.equal(got[kern], got["generic"]), f"{kern} differs from the 2-byte-store kernel"
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("case", ODD_CASES, ids=_ids(ODD_CASES))
+def test_unaligned_lengths_take_the_generic_kernel(ops, case, dtype):
+    B, H, Lq, Ls, N, Lr, inc = case
+    q, k, v, rk, rv = _case_inputs(case, dtype, seed=6)
+    p_ref = _oracle_probs(q, k, v, rk, rv, H, inc)
+    qd, kd, rkd, lse = _gpu_lse(ops, q, k, v, rk, rv, H, inc)
+    probs = ops.attn_probs(qd, kd, rkd, lse, heads=H, scale=0.125, include_self=inc)
+    assert np.abs(probs.float().cpu().numpy() - p_ref).max() <= TOL[dtype]
+    for kern in ("lines64", "lines32"):   # asked for by name on a shape it does not cover: refused, not silently replaced
+        with pytest.raises(ops._lib.IRError, match="multiples of 8"):
+            ops.attn_probs(qd, kd, rkd, lse, heads=H, scale=0.125, include_self=inc, kernel=kern)
+
+
+def test_rows_past_the_output_are_untouched(ops):
+    """canary: the line kernel's range-checked stores must not write outside (B, H, Lq, Lkv) - the buffer behind it keeps its
+    fill pattern (partial row block, key tail that is not a whole 64-key step)"""
+    dtype = torch.float16
+    case = (1, 2, 72, 72, 2, 40, True)
+    B, H, Lq, Ls, N, Lr, inc = case
+    q, k, v, rk, rv = _case_inputs(case, dtype)
+    qd, kd, rkd, lse = _gpu_lse(ops, q, k, v, rk, rv, H, inc)
+    from instantrestore_amd import _lib
+    import ctypes as C
+    lkv = Ls + N * Lr
+    n = B * H * Lq * lkv
+    big = torch.full((n + 65536,), 7.0, dtype=dtype, device="cuda")
+    args, *_keep = ops._probs_args(qd, kd, rkd, lse, H, 0.125, inc)
+    for kern in (2, 3):
+        big.fill_(7.0)
+        _lib.check(_lib.lib().ir_attn_probs_ex(C.byref(args), big.data_ptr(), kern, torch.cuda.current_stream().cuda_stream), "probs")
+        torch.cuda.synchronize()
+        assert bool((big[n:] == 7.0).all()), "stores past the end of attention_probs"
+        assert bool((big[:n] <= 1.0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("case", CASES + ODD_CASES, ids=_ids(CASES + ODD_CASES))
+def test_segment_mass(ops, case, dtype):
+    """mass[b,h,i,s] = sum of row i's probabilities over segment s, fp32, summed before the 16-bit rounding: against the
+    oracle's float64 block sums (abs 2e-3: the only 16-bit quantity left is the input rounding) and rows summing to 1"""
+    B, H, Lq, Ls, N, Lr, inc = case
+    q, k, v, rk, rv = _case_inputs(case, dtype, seed=7)
+    p_ref = _oracle_probs(q, k, v, rk, rv, H, inc)
+    if rk is None:
+        inc = True
+    edges = [0] + ([Ls] if inc else []) + [(Ls if inc else 0) + (n + 1) * Lr for n in range(N)]
+    m_ref = np.stack([p_ref[..., a:b].sum(-1) for a, b in zip(edges[:-1], edges[1:])], axis=-1)
+    qd, kd, rkd, lse = _gpu_lse(ops, q, k, v, rk, rv, H, inc)
+    mass = ops.attn_segment_mass(qd, kd, rkd, lse, heads=H, scale=0.125, include_self=inc)
+    assert mass.shape == m_ref.shape and mass.dtype == torch.float32
+    m = mass.cpu().numpy()
+    assert np.abs(m - m_ref).max() <= 2e-3, np.abs(m - m_ref).max()
+    np.testing.assert_allclose(m.sum(-1), 1.0, atol=2e-3)

@@ -82,13 +82,17 @@ def test_adain_affine_form_equals_adain():
     B, N, L, H = 2, 3, 37, 2
     v_self = rng.standard_normal((B, L, H * 64)) * 0.8 + 0.3
     ref_v = rng.standard_normal((B, N, L, H * 64)) * 1.7 - 0.5
-    ref_v[1, 2] = 0.0
+    ref_v[1, 2] = 0.0               # zero-filled reference (pix2pix_turbo.py:269-273)
+    ref_v[0, 1, :, 5:9] = 0.4375    # constant, non-zero channels: content std exactly 0, mean not
     a, b = O.adain_affine_np(v_self, ref_v, H)
     s_mean, s_std = O.token_stats_np(v_self)
     for n in range(N):
         want = O.adain_np(ref_v[:, n], s_mean, s_std + O.ADAIN_EPS)
         got = ref_v[:, n] * a[:, n][:, None, :] + b[:, n][:, None, :]
         np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+    # where the content std is exactly 0 the affine is (0, style mean): adain() returns the style mean there for any ratio
+    assert np.all(a[1, 2] == 0) and np.array_equal(b[1, 2], s_mean[1, 0])
+    assert np.all(a[0, 1, 5:9] == 0) and np.array_equal(b[0, 1, 5:9], s_mean[0, 0, 5:9])
 
 
 def test_zero_fill_is_not_masking():

@@ -594,6 +594,64 @@ def extra_graph(layers, B, N, steps):
     return sec, not bad, detail
 
 
+def extra_probs_dump(layers, B, N, train_input, dtype, dev):
+    """The dump path (attn_processors.py:258-261; what gradio_demo.py:108-109 turns on for every request): ``ir_attn_probs`` at
+    the three layer classes of the config - HIP-event time per launch, GB/s of the H*L*Lkv*2 bytes it writes, and that rate as a
+    fraction of the copy and fill rates measured HERE, now, on this box (a 1 GiB -> 1 GiB copy, a 1 GiB fill).  Plus the opt-in
+    per-segment mass (``ir_attn_segment_mass``): what a consumer that only ranks the references needs, without the tensor."""
+    from instantrestore_amd import ops as _o
+
+    def timed(fn, iters):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    n = 1 << 29
+    src = torch.empty(n, dtype=dtype, device=dev).normal_()
+    dst = torch.empty_like(src)
+    copy_gbs = 2 * n * 2 / timed(lambda: dst.copy_(src), 5) / 1e6      # bytes read + bytes written
+    fill_gbs = n * 2 / timed(lambda: dst.fill_(0.5), 5) / 1e6
+    del src, dst
+    t = 1 if train_input else 0
+    per_class, total_ms, total_bytes = [], 0.0, 0.0
+    seen = set()
+    for ly in layers:
+        L, C, H = ly["L"], ly["C"], ly["H"]
+        if (L, C) in seen:
+            continue
+        seen.add((L, C))
+        nbytes = float(B) * H * L * (N + t) * L * 2
+        if nbytes > 24e9:
+            per_class.append({"L": L, "H": H, "skipped": "%.1f GB of probabilities" % (nbytes / 1e9)})
+            continue
+        g = torch.Generator(device=dev).manual_seed(5)
+        q, k, v = (torch.randn(B, L, C, device=dev, generator=g).to(dtype) for _ in range(3))
+        rk, rv = (torch.randn(B, N, L, C, device=dev, generator=g).to(dtype) for _ in range(2))
+        _, lse = _o.shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, include_self=bool(t), return_lse=True)
+        iters = 3 if nbytes > 2e9 else 10
+        ms = timed(lambda: _o.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=bool(t)), iters)
+        ms_old = timed(lambda: _o.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=bool(t), kernel="generic"), iters)
+        ms_mass = timed(lambda: _o.attn_segment_mass(q, k, rk, lse, heads=H, scale=0.125, include_self=bool(t)), iters)
+        gbs = nbytes / ms / 1e6
+        per_class.append({"L": L, "H": H, "Lkv": (N + t) * L, "gb_written": round(nbytes / 1e9, 3), "ms": round(ms, 4), "gb_per_s": round(gbs, 1),
+                          "frac_of_copy_rate": round(gbs / copy_gbs, 3), "frac_of_fill_rate": round(gbs / fill_gbs, 3),
+                          "ms_round1_kernel_2byte_stores": round(ms_old, 4), "ms_segment_mass_only": round(ms_mass, 4)})
+        total_ms += 3 * ms
+        total_bytes += 3 * nbytes
+        del q, k, v, rk, rv, lse
+    return {"kernel": "attn_probs_lines_kernel (whole 128-B lines per store; segment lengths multiples of 8)",
+            "copy_rate_gb_per_s_measured_here": round(copy_gbs, 1), "fill_rate_gb_per_s_measured_here": round(fill_gbs, 1),
+            "layer_classes": per_class, "ms_per_step_all_nine_layers": round(total_ms, 3), "gb_per_step": round(total_bytes / 1e9, 2),
+            "note": "with save_self_attentions on, every shared layer also writes its (B, H, L, Lkv) probabilities; HBM-write bound. "
+                    "Not part of the headline step (inference/test.py:97 turns it on only for visualisation)"}
+
+
 def extra_e2e(B, N, px, dtype, steps, dev):
     """End-to-end leg on the attention-topology host (instantrestore_amd/unet_host.py: SD-Turbo's 32 attention
     processors on both UNets with the real widths; conv/ResNet bodies, VAE and caption encoder are STAND-INS, SURVEY
@@ -658,7 +716,7 @@ def extra_e2e(B, N, px, dtype, steps, dev):
                     "InstantRestore throughput"}
 
 
-def extra_scatter_gather(B_local, N, px, world, rank, dev, backend):
+def extra_scatter_gather(B_local, N, px, world, rank, dev, backend, single_rank_comm=None):
     """the batch scatter (degraded + references, fp16) and the output gather as grouped point-to-point
     transfers over the process group - RCCL send/recv when N > 1 - outside the headline timing."""
     from instantrestore_amd import sharding
@@ -683,7 +741,17 @@ def extra_scatter_gather(B_local, N, px, world, rank, dev, backend):
         g = torch.Generator().manual_seed(7)
         images = [[torch.randint(0, 256, (px, px, 3), generator=g, dtype=torch.uint8).to(dev) for _ in range(1 + N)]
                   for _ in range(total)] if rank == 0 else None
-        run = lambda: sharding.run_sharded_images(step, images, total, N, px, dt, tdev)
+        loop = bool(world == 1 and single_rank_comm and single_rank_comm.get("ok"))   # N = 1: both transfers through RCCL to this rank itself
+        run = lambda: sharding.run_sharded_images(step, images, total, N, px, dt, tdev, loopback=loop)
+        if loop:
+            try:        # same bytes as the slicing path, or the leg says so
+                a, b = run(), sharding.run_sharded_images(step, images, total, N, px, dt, tdev)
+                torch.cuda.synchronize()
+                single_rank_comm["loopback_equals_slicing"] = bool(torch.equal(a, b))
+            except Exception as e:
+                single_rank_comm.update({"ok": False, "error": "loopback send/recv: %s: %s" % (type(e).__name__, e)})
+                loop = False
+                run = lambda: sharding.run_sharded_images(step, images, total, N, px, dt, tdev)
         want_shape, path = (total, px, px, 3), "uint8 images in, Lanczos preprocess into the send buffers, uint8 pixels back"
         nbytes = (1 + N) * 3 * px * px * 2 + 3 * px * px
     for _ in range(2):
@@ -702,9 +770,15 @@ def extra_scatter_gather(B_local, N, px, world, rank, dev, backend):
         dist.barrier()
     ms = (time.perf_counter() - t0) / reps * 1e3
     ok = (out is not None and tuple(out.shape) == want_shape) if rank == 0 else out is None or world == 1
-    return {"scatter_gather_ms": round(ms, 3), "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
-            "backend": backend if world > 1 else "none (one rank: slicing only)", "path": path,
-            "bytes_per_identity_on_the_links": nbytes, "ok": bool(ok)}
+    one_rank = world == 1 and single_rank_comm and single_rank_comm.get("ok")
+    res = {"scatter_gather_ms": round(ms, 3), "rccl_ranks": (dist.get_world_size() if (world > 1 or one_rank) else 1),
+           "backend": backend if (world > 1 or one_rank) else "none (one rank: slicing only)", "path": path,
+           "bytes_per_identity_on_the_links": nbytes, "ok": bool(ok)}
+    if world == 1 and single_rank_comm is not None:
+        res["single_rank_communicator"] = dict(single_rank_comm, note="N = 1: a real one-rank RCCL communicator; barrier, MAX reduction and "
+                                               "both transfers (ncclSend + ncclRecv to this rank, one group) ran through it - no xGMI link is "
+                                               "involved and NO SCALING CURVE is measured by it")
+    return res
 
 
 def _guarded(fn, dev, seconds):
@@ -731,6 +805,29 @@ def _guarded(fn, dev, seconds):
     if th.is_alive():
         return {"error": "no result after %.0f s (watchdog)" % seconds}, True
     return box.get("r"), False
+
+
+def init_single_rank_nccl(dev):
+    """a one-rank ``nccl`` (= RCCL) process group on ``dev`` over a loopback TCP store on a free port.  Returns a report dict;
+    ``ok`` False (with the error) when RCCL could not be brought up - the caller then runs without a process group."""
+    import socket
+    try:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        t0 = time.perf_counter()
+        dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+        x = torch.ones(1, device=dev)
+        dist.all_reduce(x)          # forces the communicator into existence (lazy otherwise) and runs one RCCL kernel
+        torch.cuda.synchronize()
+        return {"ok": True, "backend": "nccl", "ranks": dist.get_world_size(), "init_s": round(time.perf_counter() - t0, 3)}
+    except Exception as e:
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+        return {"ok": False, "error": "%s: %s" % (type(e).__name__, e)}
 
 
 def self_launch(n_gpus):
@@ -833,13 +930,20 @@ def main():
     dev_index = 0 if os.environ.get("IR_BENCH_SHARE_DEVICE") == "1" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    single_rank_comm = None   # world == 1: {"backend": "nccl", ...} once a REAL one-rank RCCL communicator exists, else why not
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
         else:
             dist.init_process_group(backend=backend)
+    elif os.environ.get("IR_BENCH_FORCE_DIST", "1") == "1" and backend == "nccl":
+        # N = 1 (round 5): the barrier, the MAX-over-ranks reduction and the scatter / gather leg run through
+        # a real one-rank RCCL communicator, so that the first 8-GPU run is not also the first RCCL run.  Never at the price of
+        # the headline: any failure falls back to the plain single-process path and is reported in extras.scatter_gather.
+        single_rank_comm = init_single_rank_nccl(dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    use_dist = world > 1 or (single_rank_comm is not None and single_rank_comm.get("ok"))
 
     train_input = bool(args.train_input)
     if args.variant:
@@ -851,7 +955,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -897,7 +1001,7 @@ def main():
         in_step_ms = [a.elapsed_time(b) for a, b in in_step]
     assert all(torch.isfinite(o).all() for o in outs)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -984,6 +1088,10 @@ def main():
                     extras["power"] = power_probe(pstep, float(os.environ.get("IR_BENCH_POWER_SECONDS", "3")))
                 except Exception as e:
                     extras["power"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                try:
+                    extras["probs_dump"] = extra_probs_dump(layers, B, N, train_input, dtype, dev)
+                except Exception as e:
+                    extras["probs_dump"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 if args.config != "cfg5":
                     try:
                         extras["e2e_topology_host"] = extra_e2e(B, N, px, dtype, max(2, args.steps // 2), dev)
@@ -996,8 +1104,8 @@ def main():
         if hung:
             sg = {"error": "skipped: the ranks did not meet at the barrier before it"}
         else:
-            sg, hung = _guarded(lambda: extra_scatter_gather(B, N, px, world, rank, dev, backend), dev,
-                                float(os.environ.get("IR_BENCH_SG_TIMEOUT", "120")) if world > 1 else None)
+            sg, hung = _guarded(lambda: extra_scatter_gather(B, N, px, world, rank, dev, backend, single_rank_comm), dev,
+                                float(os.environ.get("IR_BENCH_SG_TIMEOUT", "120")) if (world > 1 or use_dist) else None)
         extras["scatter_gather"] = sg
     if world > 1 and not hung:
         _, hung = _guarded(lambda: dist.barrier(), dev, 60.0)
@@ -1052,7 +1160,8 @@ def main():
                 "identities_per_gpu": B, "global_batch": total_ids, "refs": N, "px": px,
                 "use_adain": use_adain, "train_input": train_input, "ref_early_exit": bool(args.ref_early_exit), "two_streams": bool(args.two_streams), "launch": launch_mode, "graph_capture_error": graph_error, "parallelism": "dp%d (independent identities)" % world,
                 "activations": "fp32 under torch.autocast (test.py:61-83)" if act_fp32 else "pre-cast to the 16-bit dtype",
-                "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                "rccl_ranks": (dist.get_world_size() if use_dist else 1),
+                "rccl_communicator": ("real (%d ranks)" % dist.get_world_size()) if use_dist else "none: %s" % ((single_rank_comm or {}).get("error") or "IR_BENCH_FORCE_DIST=0"),
                 "scatter_gather_ms": None if not extras else extras.get("scatter_gather", {}).get("scatter_gather_ms"),
                 "extras": extras,
                 **{k: round(v, 1) for k, v in summary(N, train_input, px).items()},
@@ -1061,6 +1170,13 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
+    if world == 1 and use_dist:
+        if hung:
+            os._exit(0)
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
     if world > 1:
         if hung:   # some rank is stuck in a collective: the line is out, leave without the teardown that would wait for it
             sys.stdout.flush()

@@ -163,8 +163,11 @@ int ir_shared_attn_fwd(const ir_shared_attn_args* args, void* stream);
 int ir_attn_probs(const ir_shared_attn_args* args, void* probs, void* stream);
 #define IR_PROBS_AUTO 0
 #define IR_PROBS_GENERIC 1   /* 2-byte stores, any length */
-#define IR_PROBS_LINES64 2   /* line kernel, 64 query rows per wave */
-#define IR_PROBS_LINES32 3   /* line kernel, 32 query rows per wave */
+#define IR_PROBS_LINES64 2       /* line kernel, 64 query rows x 64 keys (128 B per row) per wave and step */
+#define IR_PROBS_LINES32 3       /* 32 rows x 64 keys */
+#define IR_PROBS_LINES32_K128 4  /* 32 rows x 128 keys (256 B per row and store batch) */
+#define IR_PROBS_LINES64_K128 5  /* 64 rows x 128 keys */
+#define IR_PROBS_LINES32_K256 6  /* 32 rows x 256 keys (512 B per row and store batch) */
 int ir_attn_probs_ex(const ir_shared_attn_args* args, void* probs, int32_t kernel, void* stream);
 
 /*

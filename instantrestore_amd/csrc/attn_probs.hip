@@ -34,7 +34,7 @@ namespace {
 constexpr int PW = 4;  // waves per workgroup
 
 struct ProbsPlan {
-  int kc;         // keys per chunk (multiple of 64)
+  int kc;         // keys per chunk (multiple of the kernel's step)
   int nch_self;   // chunks of the self segment (0 without it)
   int nch_ref;    // chunks per reference segment
   int nch_total;  // nch_self + N * nch_ref
@@ -55,12 +55,17 @@ static __device__ __forceinline__ unsigned pack2(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-template <typename T, int NQ, bool MASS>
+template <typename T, int NQ, int NK, bool MASS>
 __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKParams p, const ProbsPlan pl, float* __restrict__ mass) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
   constexpr int ROWS = 32 * NQ;                   // query rows per wave
-  constexpr int TILE = MASS ? 16 : ROWS * 128;    // LDS bytes per wave
+  constexpr int STEP = 32 * NK;                   // keys per step
+  constexpr int PITCH = 2 * STEP;                 // bytes of one row of the wave's LDS tile (NK * 64)
+  constexpr int TILE = MASS ? 16 : ROWS * PITCH;  // LDS bytes per wave
+  constexpr int LPR = PITCH / 16;                 // lanes that read one row back (16 B each)
+  constexpr int RPI = 64 / LPR;                   // rows per store instruction
+  constexpr int NST = ROWS / RPI;                 // store instructions per step
   __shared__ __attribute__((aligned(16))) unsigned char lds_all[PW * TILE];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -108,36 +113,35 @@ __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKPa
 
   // A operand: K[key j + 32*kblk + keymap(lq)][d = 16ks + 8hi ..], keys past the segment clamped (their columns are not stored)
   const int km = keymap(lq);
-  v8 kf[2][4];
+  v8 kf[NK][4];
   auto load_k = [&](int j, int kblk) {   // one 32-key block of fragments
     const int key = j + 32 * kblk + km;
     const T* kp = kb + (int64_t)(key < len ? key : len - 1) * ksl + hi * 8;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) kf[kblk][ks] = *(const v8*)(kp + ks * 16);
   };
-  load_k(j_begin, 0);
-  load_k(j_begin, 1);
+#pragma unroll
+  for (int kblk = 0; kblk < NK; ++kblk) load_k(j_begin, kblk);
 
   unsigned char* tile = lds_all + wid * TILE;
-  // read-back role of this lane: row 8t + (lane >> 3), 16-byte chunk lane & 7 (8 keys) of the 64-key step.  Stores go through
-  // ONE buffer resource over the workgroup's rows of P (<= PW*ROWS rows: offsets stay below 2^31, launch-side check): rows
-  // past Lq fall outside num_records and are dropped by the range check, key chunks past the segment get an offset that is
-  // - so the store loop has no branch, and hipcc can count the stores in flight instead of draining them (vmcnt(0)) before
-  // the next step's K fragments are consumed
-  const int rrow = lane >> 3, rchunk = lane & 7;
+  // read-back role of this lane: row RPI*t + lane / LPR, 16-byte chunk lane % LPR (8 keys) of the step.  Stores go through ONE
+  // buffer resource over the workgroup's rows of P (<= PW*ROWS rows: offsets stay below 2^31, launch-side check): rows past
+  // Lq fall outside num_records and are dropped by the range check, key chunks past the segment get an offset that is - so
+  // the store loop has no branch, and hipcc counts the stores in flight instead of draining them around a branch
+  const int rrow = lane / LPR, rchunk = lane % LPR;
   const int wg_row0 = qb * (PW * ROWS);
   const int wg_rows = (p.Lq - wg_row0 < PW * ROWS) ? p.Lq - wg_row0 : PW * ROWS;
   __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
       (void*)((T*)p.probs + (((int64_t)b * p.H + h) * p.Lq + wg_row0) * (int64_t)p.lkv), 0, (unsigned)wg_rows * (unsigned)p.lkv * 2u, 0x00020000);
-  const unsigned row_pitch8 = (unsigned)p.lkv * 16u;   // 8 rows of P in bytes
+  const unsigned row_pitch = (unsigned)p.lkv * 2u * RPI;   // RPI rows of P in bytes
   unsigned ooff = ((unsigned)(wid * ROWS + rrow) * (unsigned)p.lkv + (unsigned)(col0 + j_begin + rchunk * 8)) * 2u;
   float msum[NQ];
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) msum[qi] = 0.f;
 
-  for (int j = j_begin; j < j_end; j += 64) {
+  for (int j = j_begin; j < j_end; j += STEP) {
 #pragma unroll
-    for (int kblk = 0; kblk < 2; ++kblk) {
+    for (int kblk = 0; kblk < NK; ++kblk) {
       f32x16 sc[NQ];
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
@@ -148,16 +152,21 @@ __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKPa
       }
       // the block's fragments are dead: the next step's arrive in the same registers while this step's exponentials run
       // (clamped past the end of the segment: always a valid address)
-      load_k(j + 64, kblk);
+      load_k(j + STEP, kblk);
 #pragma unroll
       for (int qi = 0; qi < NQ; ++qi) {
         // sc[qi][r] = <K[j + 32 kblk + 16 hi + r], Q[q0 + 32 qi + lq]>
         if constexpr (MASS) {
           const int kfirst = j + 32 * kblk + 16 * hi;
+          if (j + STEP <= j_end) {   // wave-uniform: whole steps need no key mask
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float e = fast_exp2(__builtin_fmaf(sc[qi][r], p.scale_log2, -lse2[qi]));
-            msum[qi] += (kfirst + r < j_end) ? e : 0.f;
+            for (int r = 0; r < 16; ++r) msum[qi] += fast_exp2(__builtin_fmaf(sc[qi][r], p.scale_log2, -lse2[qi]));
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float e = fast_exp2(__builtin_fmaf(sc[qi][r], p.scale_log2, -lse2[qi]));
+              msum[qi] += (kfirst + r < j_end) ? e : 0.f;
+            }
           }
         } else {
           unsigned w[8];
@@ -166,7 +175,7 @@ __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKPa
             w[r >> 1] = pack2<T>(fast_exp2(__builtin_fmaf(sc[qi][r], p.scale_log2, -lse2[qi])),
                                  fast_exp2(__builtin_fmaf(sc[qi][r + 1], p.scale_log2, -lse2[qi])));
           const int R = 32 * qi + lq;
-          unsigned char* rowp = tile + R * 128;
+          unsigned char* rowp = tile + R * PITCH;
           const int c0 = kblk * 4 + hi * 2;
           *(u32x4_alias*)(rowp + (((c0 + 0) ^ (R & 7)) << 4)) = u32x4{w[0], w[1], w[2], w[3]};
           *(u32x4_alias*)(rowp + (((c0 + 1) ^ (R & 7)) << 4)) = u32x4{w[4], w[5], w[6], w[7]};
@@ -176,16 +185,16 @@ __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKPa
     if constexpr (!MASS) {
       ir_wave_lds_fence();
       const unsigned obase = (j + rchunk * 8 < j_end) ? ooff : 0x80000000u;
-      u32x4 v[4 * NQ];
+      u32x4 v[NST];
 #pragma unroll
-      for (int t = 0; t < 4 * NQ; ++t) {
-        const int R = 8 * t + rrow;
-        v[t] = *(const u32x4_alias*)(tile + R * 128 + ((rchunk ^ (R & 7)) << 4));
+      for (int t = 0; t < NST; ++t) {
+        const int R = RPI * t + rrow;
+        v[t] = *(const u32x4_alias*)(tile + R * PITCH + ((rchunk ^ (R & 7)) << 4));
       }
       ir_wave_lds_fence();   // every read issued before the first store waits for its data
 #pragma unroll
-      for (int t = 0; t < 4 * NQ; ++t) __builtin_amdgcn_raw_buffer_store_b128(v[t], prs, obase + (unsigned)t * row_pitch8, 0, 0);
-      ooff += 128u;
+      for (int t = 0; t < NST; ++t) __builtin_amdgcn_raw_buffer_store_b128(v[t], prs, obase + (unsigned)t * row_pitch, 0, 0);
+      ooff += (unsigned)PITCH;
     }
   }
 
@@ -277,11 +286,11 @@ static int device_cus() {
 }
 
 // Cut of the key axis: the largest chunk (whole segments first) that still leaves >= 16 workgroups per CU; never below 256 keys.
-static ProbsPlan make_plan(const AttnKParams& p, int rows_per_wg, bool whole_segments) {
+static ProbsPlan make_plan(const AttnKParams& p, int rows_per_wg, int step, bool whole_segments) {
   ProbsPlan pl;
   pl.nqb = (p.Lq + rows_per_wg - 1) / rows_per_wg;
   const int maxlen = (p.include_self && p.Ls > p.Lr) || p.N == 0 ? p.Ls : p.Lr;
-  int kc = (maxlen + 63) / 64 * 64;
+  int kc = (maxlen + step - 1) / step * step;
   if (!whole_segments) {
     const int64_t want = (int64_t)16 * device_cus();
     for (;;) {
@@ -289,7 +298,7 @@ static ProbsPlan make_plan(const AttnKParams& p, int rows_per_wg, bool whole_seg
       const int64_t nr = p.N > 0 ? (p.Lr + kc - 1) / kc : 0;
       const int64_t items = (int64_t)p.B * p.H * pl.nqb * (ns + (int64_t)p.N * nr);
       if (items >= want || kc <= 256) break;
-      kc = ((kc / 2) + 63) / 64 * 64;
+      kc = ((kc / 2) + step - 1) / step * step;
     }
   }
   pl.kc = kc;
@@ -313,21 +322,32 @@ static bool lines_ok(const AttnKParams& p) {
 
 bool ir_attn_probs_uses_lines(const AttnKParams& p) { return lines_ok(p); }
 
+namespace {
+template <typename T, int NQ, int NK>
+hipError_t launch_lines(const AttnKParams& p, hipStream_t s) {
+  const ProbsPlan pl = make_plan(p, PW * 32 * NQ, 32 * NK, false);
+  if (pl.items <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((attn_probs_lines_kernel<T, NQ, NK, false>), dim3(pl.items), dim3(PW * 64), 0, s, p, pl, (float*)nullptr);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_lines_variant(const AttnKParams& p, int variant, hipStream_t s) {
+  switch (variant) {
+    case 2: return launch_lines<T, 2, 2>(p, s);   // 64 rows x 128 B per wave and step
+    case 3: return launch_lines<T, 1, 2>(p, s);   // 32 rows x 128 B
+    case 4: return launch_lines<T, 1, 4>(p, s);   // 32 rows x 256 B
+    case 5: return launch_lines<T, 2, 4>(p, s);   // 64 rows x 256 B
+    case 6: return launch_lines<T, 1, 8>(p, s);   // 32 rows x 512 B
+    default: return hipErrorInvalidValue;
+  }
+}
+}  // namespace
+
 hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
   if (variant != 1 && lines_ok(p)) {
-    // 64 rows per wave; 32 when the rows of one (b, h) would not fill a 256-row workgroup (the 16 x 16-token class)
-    const bool nq2 = variant == 3 ? false : (variant == 2 ? true : p.Lq >= 256);
-    const ProbsPlan pl = make_plan(p, PW * (nq2 ? 64 : 32), false);
-    if (pl.items <= 0) return hipErrorInvalidValue;
-    const dim3 grid(pl.items), block(PW * 64);
-    if (dtype == 1) {
-      if (nq2) hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 2, false>), grid, block, 0, s, p, pl, (float*)nullptr);
-      else hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 1, false>), grid, block, 0, s, p, pl, (float*)nullptr);
-    } else {
-      if (nq2) hipLaunchKernelGGL((attn_probs_lines_kernel<_Float16, 2, false>), grid, block, 0, s, p, pl, (float*)nullptr);
-      else hipLaunchKernelGGL((attn_probs_lines_kernel<_Float16, 1, false>), grid, block, 0, s, p, pl, (float*)nullptr);
-    }
-    return hipGetLastError();
+    // automatic: 64 rows per wave; 32 when the rows of one (b, h) would not fill a 256-row workgroup (the 16 x 16-token class)
+    const int v = variant >= 2 ? variant : (p.Lq >= 256 ? 2 : 3);
+    return dtype == 1 ? launch_lines_variant<__bf16>(p, v, s) : launch_lines_variant<_Float16>(p, v, s);
   }
   if (variant >= 2) return hipErrorInvalidValue;   // the line kernel was asked for by name and does not cover the shape
   const int nqb = (p.Lq + PW * 32 - 1) / (PW * 32);
@@ -339,15 +359,15 @@ hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, int variant, hi
 
 hipError_t ir_launch_attn_segment_mass(const AttnKParams& p, int dtype, float* mass, hipStream_t s) {
   const bool nq2 = p.Lq >= 256;
-  const ProbsPlan pl = make_plan(p, PW * (nq2 ? 64 : 32), true);   // whole segments: one writer per (row, segment), no reduction through memory
+  const ProbsPlan pl = make_plan(p, PW * (nq2 ? 64 : 32), 64, true);   // whole segments: one writer per (row, segment), no reduction through memory
   if (pl.items <= 0) return hipErrorInvalidValue;
   const dim3 grid(pl.items), block(PW * 64);
   if (dtype == 1) {
-    if (nq2) hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 2, true>), grid, block, 0, s, p, pl, mass);
-    else hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 1, true>), grid, block, 0, s, p, pl, mass);
+    if (nq2) hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 2, 2, true>), grid, block, 0, s, p, pl, mass);
+    else hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 1, 2, true>), grid, block, 0, s, p, pl, mass);
   } else {
-    if (nq2) hipLaunchKernelGGL((attn_probs_lines_kernel<_Float16, 2, true>), grid, block, 0, s, p, pl, mass);
-    else hipLaunchKernelGGL((attn_probs_lines_kernel<_Float16, 1, true>), grid, block, 0, s, p, pl, mass);
+    if (nq2) hipLaunchKernelGGL((attn_probs_lines_kernel<_Float16, 2, 2, true>), grid, block, 0, s, p, pl, mass);
+    else hipLaunchKernelGGL((attn_probs_lines_kernel<_Float16, 1, 2, true>), grid, block, 0, s, p, pl, mass);
   }
   return hipGetLastError();
 }

@@ -17,6 +17,9 @@ for s in "${SRCS[@]}"; do
   extra=()
   # the 64-row kernels need scalar (single-issue) fp32 code where the SLP vectoriser would form v_pk_* operations
   [[ "$s" == shared_attn_fwd_w64.hip ]] && extra+=(-fno-slp-vectorize)
+  # the dump kernels exponentiate every MFMA result on the VALU: MFMA destinations in VGPRs (hipcc's default puts them in AGPRs
+  # and copies each one out with v_accvgpr_read: 96 of 271 vector instructions per 64 x 64 tile, profiles/r5_pmc_probs.txt)
+  [[ "$s" == attn_probs.hip ]] && extra+=(-mllvm -amdgpu-mfma-vgpr-form)
   # resource remarks (registers, spills, scratch per kernel) go to <build dir>/<source>.remarks: tools/check_resources.py reads them
   "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage "${extra[@]}" "$@" -c "$s" -o "$o" 2> "${BUILD_DIR}/${s%.hip}.remarks" &
   pids+=($!)

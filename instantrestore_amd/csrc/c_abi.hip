@@ -195,7 +195,7 @@ int ir_attn_probs_ex(const ir_shared_attn_args* args, void* probs, int32_t kerne
   const int rc = build_attn_params(args, &p, false);
   if (rc != IR_OK) return rc;
   if (probs == nullptr || args->lse == nullptr) return fail(IR_ERR_INVALID_ARG, "probs/lse is NULL");
-  if (kernel < IR_PROBS_AUTO || kernel > IR_PROBS_LINES32) return fail(IR_ERR_UNSUPPORTED, "attn_probs kernel %d", kernel);
+  if (kernel < IR_PROBS_AUTO || kernel > IR_PROBS_LINES32_K256) return fail(IR_ERR_UNSUPPORTED, "attn_probs kernel %d", kernel);
   p.probs = probs;
   if (kernel >= IR_PROBS_LINES64 && !ir_attn_probs_uses_lines(p))
     return fail(IR_ERR_UNSUPPORTED, "the line kernel needs len_self, len_ref (and so Lkv) to be multiples of 8 and probs 16-byte aligned");

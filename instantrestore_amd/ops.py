@@ -256,7 +256,7 @@ def shared_attention_kernel_name(q, k_self, v_self, ref_k=None, ref_v=None, *, h
     return _lib.lib().ir_shared_attn_kernel_name(C.byref(args)).decode()
 
 
-PROBS_KERNELS = {"auto": 0, "generic": 1, "lines64": 2, "lines32": 3}   # IR_PROBS_*
+PROBS_KERNELS = {"auto": 0, "generic": 1, "lines64": 2, "lines32": 3, "lines32k128": 4, "lines64k128": 5, "lines32k256": 6}   # IR_PROBS_*
 
 
 def _probs_args(q, k_self, ref_k, lse, heads, scale, include_self):

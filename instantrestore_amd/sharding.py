@@ -39,13 +39,30 @@ def _world(group) -> Tuple[int, int]:
     return dist.get_world_size(group), dist.get_rank(group)
 
 
+def _loopback(t: torch.Tensor, group) -> torch.Tensor:
+    """one rank, ``loopback``: the shard travels through ONE grouped send/recv pair addressed to this rank itself - with the
+    ``nccl`` backend an ``ncclSend`` + ``ncclRecv`` inside one RCCL group on the real communicator.  No reference counterpart
+    and no use in production (a one-rank job slices); it exists so that the transfer code path of the N > 1 job - communicator,
+    group launch, stream ordering - has executed on every box the single-GPU bench and tests run on."""
+    if dist.get_backend(group) != "nccl":
+        raise RuntimeError("loopback transfers need the nccl (RCCL) backend: gloo has no pair to the calling rank itself")
+    src = t.contiguous()
+    dst = torch.empty_like(src)
+    me = dist.get_rank(group)
+    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, src, me, group), dist.P2POp(dist.irecv, dst, me, group)]):
+        req.wait()
+    return dst
+
+
 def scatter_identities(full: Optional[torch.Tensor], total: int, tail_shape: Sequence[int], dtype: torch.dtype,
-                       device: torch.device, src: int = 0, group=None) -> torch.Tensor:
+                       device: torch.device, src: int = 0, group=None, loopback: bool = False) -> torch.Tensor:
     """Rank ``src`` holds ``full`` of shape ``(total, *tail_shape)``; every rank returns its
     contiguous shard.  One grouped batch of point-to-point transfers (one peer per link)."""
     world, rank = _world(group)
     lo, hi = shard_range(total, world, rank)
     if world == 1:
+        if loopback and dist.is_available() and dist.is_initialized():
+            return _loopback(full[lo:hi], group)
         return full[lo:hi]
     ops, keep = [], []
     if rank == src:
@@ -70,10 +87,12 @@ def scatter_identities(full: Optional[torch.Tensor], total: int, tail_shape: Seq
     return mine
 
 
-def gather_identities(shard: torch.Tensor, total: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+def gather_identities(shard: torch.Tensor, total: int, dst: int = 0, group=None, loopback: bool = False) -> Optional[torch.Tensor]:
     """Inverse of :func:`scatter_identities`: rank ``dst`` returns ``(total, ...)``, others None."""
     world, rank = _world(group)
     if world == 1:
+        if loopback and dist.is_available() and dist.is_initialized():
+            return _loopback(shard, group)
         return shard
     ops = []
     out = None
@@ -106,7 +125,7 @@ def run_sharded(step_fn, degraded: Optional[torch.Tensor], refs: Optional[torch.
 
 
 def run_sharded_images(step_fn, images, total: int, n_refs: int, size: int, dtype: torch.dtype, device: torch.device,
-                       preprocess=None, to_image=None, group=None):
+                       preprocess=None, to_image=None, group=None, loopback: bool = False):
     """The caller's whole per-batch data path with the image kernels fused into the shard transfers:
 
     rank 0 holds ``images``: ``total`` identities, each a sequence of ``1 + n_refs`` ``uint8`` ``(H, W, 3)`` tensors
@@ -119,7 +138,8 @@ def run_sharded_images(step_fn, images, total: int, n_refs: int, size: int, dtyp
     ``ops.tensor2im_u8``: the reference's ``tensor2im``, vis_utils.py:14-23, on the device) BEFORE the gather, so ``uint8``
     ``(b, S, S, 3)`` pixels travel back - a third of the fp16 tensor's bytes.  Rank 0 returns ``(total, S, S, 3)`` uint8,
     the others ``None``.  ``preprocess`` / ``to_image`` are injectable for the CPU (gloo) tests: the HIP ones have no CPU
-    fallback."""
+    fallback.  ``loopback``: on ONE rank with an initialised process group, send both transfers through the communicator
+    to this rank itself (:func:`_loopback`) instead of slicing - same bytes out."""
     world, rank = _world(group)
     if preprocess is None:
         from .preprocess import LanczosPreprocessor
@@ -133,9 +153,9 @@ def run_sharded_images(step_fn, images, total: int, n_refs: int, size: int, dtyp
             raise ValueError("rank 0 must pass `total` identities of 1 + n_refs images each")
         flat = [im for ident in images for im in ident]                  # identity-major: shards are contiguous
         packed = preprocess(flat).view(total, 1 + n_refs, 3, size, size)
-    shard = scatter_identities(packed, total, (1 + n_refs, 3, size, size), dtype, device, 0, group)
+    shard = scatter_identities(packed, total, (1 + n_refs, 3, size, size), dtype, device, 0, group, loopback)
     out = step_fn(shard[:, 0], shard[:, 1:])
     pixels = to_image(out)                                               # (b, S, S, 3) uint8
     if pixels.dtype != torch.uint8:
         raise TypeError("to_image must return uint8 pixels")
-    return gather_identities(pixels, total, 0, group)
+    return gather_identities(pixels, total, 0, group, loopback)

@@ -15,6 +15,7 @@ from oracle import shared_attn_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+LINE_KERNELS = ("lines64", "lines32", "lines32k128", "lines64k128", "lines32k256")   # IR_PROBS_LINES*: rows x keys per wave and step
 
 
 @pytest.fixture(scope="module")
@@ -87,7 +88,7 @@ def test_every_probs_kernel_against_the_oracle(ops, case, dtype):
     p_ref = _oracle_probs(q, k, v, rk, rv, H, inc)
     qd, kd, rkd, lse = _gpu_lse(ops, q, k, v, rk, rv, H, inc)
     got = {}
-    for kern in ("auto", "generic", "lines64", "lines32"):
+    for kern in ("auto", "generic") + LINE_KERNELS:
         probs = ops.attn_probs(qd, kd, rkd, lse, heads=H, scale=0.125, include_self=inc, kernel=kern)
         assert probs.shape == p_ref.shape and probs.dtype == dtype
         p = probs.float().cpu().numpy()
@@ -95,7 +96,7 @@ def test_every_probs_kernel_against_the_oracle(ops, case, dtype):
         assert np.abs(p - p_ref).max() <= TOL[dtype], (kern, np.abs(p - p_ref).max())
         np.testing.assert_allclose(p.sum(-1), 1.0, atol=4 * TOL[dtype])
         got[kern] = probs
-    for kern in ("auto", "lines64", "lines32"):
+    for kern in ("auto",) + LINE_KERNELS:
         assert torch.equal(got[kern], got["generic"]), f"{kern} differs from the 2-byte-store kernel"
 
 
@@ -108,7 +109,7 @@ def test_unaligned_lengths_take_the_generic_kernel(ops, case, dtype):
     qd, kd, rkd, lse = _gpu_lse(ops, q, k, v, rk, rv, H, inc)
     probs = ops.attn_probs(qd, kd, rkd, lse, heads=H, scale=0.125, include_self=inc)
     assert np.abs(probs.float().cpu().numpy() - p_ref).max() <= TOL[dtype]
-    for kern in ("lines64", "lines32"):   # asked for by name on a shape it does not cover: refused, not silently replaced
+    for kern in LINE_KERNELS:   # asked for by name on a shape it does not cover: refused, not silently replaced
         with pytest.raises(ops._lib.IRError, match="multiples of 8"):
             ops.attn_probs(qd, kd, rkd, lse, heads=H, scale=0.125, include_self=inc, kernel=kern)
 
@@ -127,7 +128,7 @@ def test_rows_past_the_output_are_untouched(ops):
     n = B * H * Lq * lkv
     big = torch.full((n + 65536,), 7.0, dtype=dtype, device="cuda")
     args, *_keep = ops._probs_args(qd, kd, rkd, lse, H, 0.125, inc)
-    for kern in (2, 3):
+    for kern in (2, 3, 4, 5, 6):
         big.fill_(7.0)
         _lib.check(_lib.lib().ir_attn_probs_ex(C.byref(args), big.data_ptr(), kern, torch.cuda.current_stream().cuda_stream), "probs")
         torch.cuda.synchronize()

@@ -56,7 +56,7 @@ for (L, H) in ((256 * f, 20), (1024 * f, 10), (4096 * f, 5)):
             continue
         ref = None
         line = f"L={L:5d} H={H:2d} t={t} Lkv={lkv:6d} {nbytes / 1e9:6.2f} GB :"
-        for kern in ("generic", "lines64", "lines32"):
+        for kern in ("generic", "lines64", "lines32", "lines32k128", "lines64k128", "lines32k256"):
             iters = 3 if nbytes > 2e9 else 10
             ms = timeit(lambda: ops.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=inc, kernel=kern), iters=iters, warm=1)
             p = ops.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=inc, kernel=kern)

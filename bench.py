@@ -1170,6 +1170,14 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
+    if use_dist:
+        # librccl announces itself ("Librccl path : ...") through C stdio on STDOUT, buffered until exit when stdout is a pipe:
+        # the one JSON line is out and flushed, whatever the C runtime still holds goes to stderr
+        sys.stdout.flush()
+        try:
+            os.dup2(2, 1)
+        except OSError:
+            pass
     if world == 1 and use_dist:
         if hung:
             os._exit(0)

@@ -127,8 +127,9 @@ typedef struct ir_shared_attn_args {
 #define IR_TUNE_W64X4 12
 #define IR_TUNE_W64X8 13
 #define IR_TUNE_PIPE32_EARLYQK 14
-#define IR_TUNE_SP64 16   /* development builds (-DIR_ABLATIONS) only: the one-wave-per-SIMD experiment */
-#define IR_TUNE_TP32 17   /* development builds (-DIR_ABLATIONS) only: the three-stage 32-row experiment */
+#define IR_TUNE_W64_ABL_FIRST 20 /* 20 ... : development builds (-DIR_ABLATIONS) only - energy / timing ablations of the 64-row kernel
+                                    (WRONG results: one class of work removed per bit; tools/gpu_energy_probe.py).  Values 16 / 17
+                                    (rounds 2-3: one-wave-per-SIMD and three-stage experiments) are retired. */
 #define IR_TUNE_PIPE32_POSTCHECK 18   /* 32-row kernel, pre-scaled Q, reference checked after the exponentials (needs
                                          IR_FLAG_Q_PRESCALED; parity-green, same speed as PIPE32_PRESCALE_Q: opt-in) */
 

@@ -65,8 +65,8 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->include_self = inc ? 1 : 0;
   p->q_prescaled = (a->flags & IR_FLAG_Q_PRESCALED) ? 1 : 0;
   p->out_f32 = (a->flags & IR_FLAG_OUT_F32) ? 1 : 0;
-  if (p->q_prescaled && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q && a->tuning != IR_TUNE_TP32 &&
-      a->tuning != IR_TUNE_PIPE32_POSTCHECK)
+  if (p->q_prescaled && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q &&
+      a->tuning != IR_TUNE_PIPE32_POSTCHECK && !(a->tuning >= IR_TUNE_W64_ABL_FIRST && a->tuning < IR_TUNE_W64_ABL_FIRST + 16))
     return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8, PIPE32_PRESCALE_Q and PIPE32_POSTCHECK kernels only");
   if (!p->q_prescaled && a->tuning == IR_TUNE_PIPE32_POSTCHECK)
     return fail(IR_ERR_UNSUPPORTED, "IR_TUNE_PIPE32_POSTCHECK needs IR_FLAG_Q_PRESCALED (its scores must already carry the reference)");
@@ -114,12 +114,9 @@ const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
     case 12: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 4 waves>";
     case 13: return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, AdaIN ratio-frame fold>" : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves>";
     case 11: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max, pre-scaled Q (Q rounded in the kernel)>";
-    case 16: return "shared_attn_fwd_sp_kernel<64 rows/wave, one wave per SIMD, software-pipelined>";
-    case 17: return "shared_attn_fwd_tp_kernel<32 rows/wave, 8 waves, three-stage pipeline, MFMA/VALU interleave>";
     case 14: return fold ? "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK, AdaIN fold>" : "shared_attn_fwd_pipe_kernel<4 waves, lazy max, early QK>";
     case 10: return "shared_attn_fwd_pipe_kernel<4 waves, lazy max>";
     case 7: return "shared_attn_fwd_pipe_kernel<4 waves, exact rescale>";
-    case 8: return "shared_attn_fwd_pp_kernel";
     default: return "shared_attn_fwd (tuning variant)";
   }
 }
@@ -538,16 +535,6 @@ static int linear_fwd_impl(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n
   if (kernel == IR_LIN_X_STATIONARY) {
     if (!x_stationary_covers(n, k, bias))
       return fail(IR_ERR_UNSUPPORTED, "X-stationary kernel: K in {64,...,320} or 640, N %% 32 == 0, N <= %d with bias (K = %d, N = %d)", kLinearMaxBiasN, k, n);
-#ifdef IR_ABLATIONS   // tools/experiments/linear_xs_{pp,rot}.hip: development builds only
-  } else if (kernel == IR_LIN_X_STATIONARY_PP) {
-    if ((int64_t)m * y_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "X-stationary ping-pong kernel: Y spans 2 GiB or more");
-    if (!ir_linear_xs_pp_covers(n, k, bias != nullptr))
-      return fail(IR_ERR_UNSUPPORTED, "X-stationary ping-pong kernel: K = 320, N %% 32 == 0, N <= %d with bias (K = %d, N = %d)", kLinearMaxBiasN, k, n);
-  } else if (kernel == IR_LIN_X_STATIONARY_ROT) {
-    if ((int64_t)m * y_ld * 2 >= (1LL << 31)) return fail(IR_ERR_UNSUPPORTED, "X-stationary rotated kernel: Y spans 2 GiB or more");
-    if (!ir_linear_xs_rot_covers(n, k, bias != nullptr))
-      return fail(IR_ERR_UNSUPPORTED, "X-stationary rotated kernel: K = 320, N %% 32 == 0, N <= %d with bias (K = %d, N = %d)", kLinearMaxBiasN, k, n);
-#endif
   } else if (kernel < IR_LIN_TILED_FIRST || kernel >= IR_LIN_TILED_FIRST + IR_LIN_TILE_COUNT) {
     return fail(IR_ERR_INVALID_ARG, "kernel %d: 0 auto, 1 X-stationary, %d..%d tiled", kernel, IR_LIN_TILED_FIRST, IR_LIN_TILED_FIRST + IR_LIN_TILE_COUNT - 1);
   } else if (k % 64 != 0 || !ir_linear_tiled_cfg_ok(kernel - IR_LIN_TILED_FIRST, n)) {
@@ -580,10 +567,6 @@ static int linear_fwd_impl(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n
     p.st_ws = st_ws; p.st_col0 = st_col0; p.st_cols = st_cols;
   }
   const hipError_t e =
-#ifdef IR_ABLATIONS
-      kernel == IR_LIN_X_STATIONARY_PP    ? ir_launch_linear_xs_pp(p, dtype, (hipStream_t)stream)
-      : kernel == IR_LIN_X_STATIONARY_ROT ? ir_launch_linear_xs_rot(p, dtype, (hipStream_t)stream) :
-#endif
       kernel == IR_LIN_X_STATIONARY ? ir_launch_linear_skinny(p, dtype, (hipStream_t)stream)
                                     : ir_launch_linear_tiled(p, dtype, kernel - IR_LIN_TILED_FIRST, (hipStream_t)stream);
   if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "linear launch: %s", hipGetErrorString(e));

@@ -93,9 +93,11 @@ hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hip
 hipError_t ir_launch_shared_attn_combine(const AttnKParams& p, int dtype, int qb, int rem, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s);
-hipError_t ir_launch_shared_attn_fwd_w64x8_pp(const AttnKParams& p, int dtype, hipStream_t s);
-hipError_t ir_launch_shared_attn_fwd_sp(const AttnKParams& p, int dtype, hipStream_t s);
-hipError_t ir_launch_shared_attn_fwd_tp(const AttnKParams& p, int dtype, hipStream_t s);
+#ifdef IR_ABLATIONS   // energy / timing ablations of the 64-row QS kernel (tuning values 20 + index; shared_attn_fwd_w64.hip)
+hipError_t ir_launch_shared_attn_fwd_w64_abl(const AttnKParams& p, int dtype, int index, hipStream_t s);
+int ir_w64_abl_count(void);
+int ir_w64_abl_mask(int index);
+#endif
 bool ir_attn_default_is_w64(const AttnKParams& p);
 bool ir_attn_variant_available(int variant);
 
@@ -113,7 +115,6 @@ static inline int ir_pick_split(int rem, int slots, int kmax, long cap_pieces) {
   }
   return best_k;
 }   // the default dispatch rule (variant 0)
-hipError_t ir_launch_shared_attn_fwd_pp(const AttnKParams& p, int dtype, hipStream_t s);
 // variant: 0 = automatic (line kernel when every segment length is a multiple of 8), 1 = round 1's 2-byte-store kernel,
 // 2 / 3 = the line kernel with 64 / 32 query rows per wave
 hipError_t ir_launch_attn_probs(const AttnKParams& p, int dtype, int variant, hipStream_t s);
@@ -188,13 +189,6 @@ struct LinearKParams {
   int32_t st_col0, st_cols;
 };
 hipError_t ir_launch_linear_skinny(const LinearKParams& p, int dtype, hipStream_t s);
-#ifdef IR_ABLATIONS   // development builds (tools/experiments/build.sh): two other schedules of the K = 320 case, kernel ids 9 and 10
-constexpr int IR_LIN_X_STATIONARY_PP = 9, IR_LIN_X_STATIONARY_ROT = 10;
-hipError_t ir_launch_linear_xs_pp(const LinearKParams& p, int dtype, hipStream_t s);    // ping-pong wave groups
-bool ir_linear_xs_pp_covers(int N, int K, bool has_bias);
-hipError_t ir_launch_linear_xs_rot(const LinearKParams& p, int dtype, hipStream_t s);   // row blocks rotated: staging / stores between the MFMAs
-bool ir_linear_xs_rot_covers(int N, int K, bool has_bias);
-#endif
 
 // ---- linear_tiled.hip: LDS-tiled Y = X W^T (+ bias) for any K % 64 == 0, N % 64 == 0 (K = 1280, small-M shapes) ----
 enum {   // tile shapes (rows x columns of Y per workgroup); values are the `kernel` argument of ir_linear_fwd_ex minus 2

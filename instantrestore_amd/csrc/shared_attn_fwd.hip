@@ -415,15 +415,17 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 //   14 10 with the next tile's QK^T issued before the row max
 //   18 11 with the reference checked after the exponentials (no row max on ordinary tiles; K ring of 3)
 // Development builds only (tools/experiments/build.sh, -DIR_ABLATIONS; documented experiments, NOTES.md): 1/2 this file's
-// straight-line kernel with 8 / 4 waves, 3/4 pipelined with register staging, 6 pipelined + builtin LDS-DMA, 8 ping-pong
-// wave groups (shared_attn_fwd_pp.hip), 9 straight schedule at 3 waves/SIMD, 15 the 64-row kernel with rotated phases,
-// 16 (IR_TUNE_SP64) one wave per SIMD with a spelled-out interleave, 17 (IR_TUNE_TP32) three-stage 32-row pipeline;
-// variant >> 5: ablation bits (timing experiments, WRONG results).  Those variants write 16-bit results only: they are
-// rejected together with IR_FLAG_OUT_F32.
+// straight-line kernel with 8 / 4 waves, 3/4 pipelined with register staging, 6 pipelined + builtin LDS-DMA, 9 straight
+// schedule at 3 waves/SIMD; 20-28 the energy / timing ablations of the 64-row QS kernel (shared_attn_fwd_w64.hip, WRONG
+// results); variant >> 5: ablation bits of the 32-row kernels (timing experiments, WRONG results).  Those variants write
+// 16-bit results only: they are rejected together with IR_FLAG_OUT_F32.  (Rounds 1-3 also carried 8 ping-pong wave groups,
+// 15 the 64-row kernel with rotated phases, 16 one wave per SIMD, 17 a three-stage 32-row pipeline: measured negative
+// results - NOTES.md 4.1b, 4.1b', profiles/r1_pp_phase_trace.txt, r2_sp_ablation.txt - whose sources were second copies of
+// product kernel bodies and left the tree in round 5.)
 bool ir_attn_variant_available(int variant) {
   const int base = variant & 31;
 #ifdef IR_ABLATIONS
-  return base <= 18;
+  return (base <= 18 && base != 8 && base != 15 && base != 16 && base != 17) || (base >= 20 && base < 20 + ir_w64_abl_count());
 #else
   if ((variant >> 5) != 0) return false;
   return base == 0 || base == 7 || (base >= 10 && base <= 14) || base == 18;   // 16 (SP64) and 17 (TP32): development builds, like 1-6, 8, 9, 15
@@ -442,7 +444,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
 #ifdef IR_ABLATIONS
   {   // the experiments that never learned IR_FLAG_OUT_F32 would write 16-bit data into an fp32 buffer
     const int b0 = variant & 31;
-    if (p.out_f32 && (b0 == 1 || b0 == 2 || b0 == 8 || b0 == 15 || (variant >> 5) != 0)) return hipErrorInvalidValue;
+    if (p.out_f32 && (b0 == 1 || b0 == 2 || b0 >= 20 || (variant >> 5) != 0)) return hipErrorInvalidValue;
   }
   const int abl = variant >> 5;
   if (abl != 0 && (variant & 31) == 3) return ir_launch_shared_attn_fwd_pipe_abl(p, abl, s);
@@ -463,8 +465,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
   // 32-row kernel's reference-through-C form for every other shape.  fp32 output (IR_FLAG_OUT_F32): every product kernel
   // stores its result before the rounding when asked - what the parity tests look at is the kernel that ships
 #ifdef IR_ABLATIONS
-  if (base == 17) return ir_launch_shared_attn_fwd_tp(p, dtype, s);
-  if (base == 16) return ir_launch_shared_attn_fwd_sp(p, dtype, s);
+  if (base >= 20) return ir_launch_shared_attn_fwd_w64_abl(p, dtype, base - 20, s);
 #endif
   if (p.q_prescaled) {
     if ((base == 0 && ir_attn_default_is_w64(p)) || base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
@@ -485,8 +486,6 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
     case 3: return ir_launch_shared_attn_fwd_pipe(p, dtype, 4, s);   // register staging, 4 waves
     case 4: return ir_launch_shared_attn_fwd_pipe(p, dtype, 8, s);   // register staging, 8 waves
     case 6: case 9: return ir_launch_shared_attn_fwd_pipe(p, dtype, base, s);
-    case 8: return ir_launch_shared_attn_fwd_pp(p, dtype, s);
-    case 15: return ir_launch_shared_attn_fwd_w64x8_pp(p, dtype, s);
     case 1: case 2: {
       const int nw = (base == 1) ? 8 : 4;
       return dtype == 1 ? launch_t<__bf16>(p, nw, s) : launch_t<_Float16>(p, nw, s);

@@ -37,7 +37,14 @@ struct RowBlock {
 // reference) and the scale-and-subtract multiply-add per score disappears (64 of ~236 VALU instructions per wave and
 // tile).  The two reference blocks take the registers of the Q fragments, which move to a wave-private LDS copy and
 // are read per tile next to the K fragments.
-template <typename T, bool FOLD, int NW = 4, bool QS = false>
+// ABL (development builds, -DIR_ABLATIONS, tuning values 20-28; always 0 in the product library): ENERGY / TIMING ablations of
+// the QS form - each bit removes one class of work and leaves a kernel with WRONG results but the same matrix skeleton, so
+// that joules per launch can be attributed class by class (tools/gpu_energy_probe.py, profiles/r5_energy_budget.txt):
+//   1 no LDS-DMA after the prologue (both ring slots filled once, the tiles alternate)   2 no per-tile barrier
+//   4 Q fragments read from LDS once per tile instead of four times                      8 no exponentials
+//  16 no row sums (and no outgrown-reference check)                                      32 no fp32 -> 16-bit conversions
+constexpr int W64_ABL_NODMA = 1, W64_ABL_NOBAR = 2, W64_ABL_QREUSE = 4, W64_ABL_NOEXP = 8, W64_ABL_NOSUM = 16, W64_ABL_NOPACK = 32;
+template <typename T, bool FOLD, int NW = 4, bool QS = false, int ABL = 0>
 __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
@@ -320,7 +327,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 #pragma unroll
   for (int c = 0; c < CH; ++c) { kvo[c] += (unsigned)(t0 * kstep); vvo[c] += (unsigned)(t0 * vstep); }
   issue_pair(0);
-  if (RING == 3 && NTILES > 1) issue_pair(1);
+  if ((RING == 3 || (ABL & W64_ABL_NODMA)) && NTILES > 1) issue_pair(1);
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qA[ks]), "v"(qB[ks]));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -352,8 +359,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         if (ks < 3) {
           kn0 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + kread[ks + 1]);
           kn1 = *(const IR_LDS v8*)(IR_LDS unsigned char*)(Kb + 32 * 128 + kread[ks + 1]);
-          qan = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (ks + 1) * 1024);
-          qbn = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + ks + 1) * 1024);
+          if (!(ABL & W64_ABL_QREUSE)) {
+            qan = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (ks + 1) * 1024);
+            qbn = *(const IR_LDS v8*)(IR_LDS unsigned char*)(ql + (4 + ks + 1) * 1024);
+          }
         }
         if (QLDS) __builtin_amdgcn_sched_barrier(0);
         if (QS && ks == 0) {
@@ -415,7 +424,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   int cur = 0;
   for (int t = 0; t < NTILES; ++t) {
     // pair t+RING-1 goes into the slot that was last read in step t-1
-    if (t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
+    if (!(ABL & W64_ABL_NODMA) && t + RING - 1 < NTILES) issue_pair(RING == 3 ? (cur >= 1 ? cur - 1 : 2) : (cur ^ 1));
 
     const unsigned char* Kb = smem + K_OFF + cur * TILE_BYTES;
     f32x16 sa0, sa1, sb0, sb1;
@@ -443,6 +452,13 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         }
       };
       auto pack = [&](f32x16& s0, f32x16& s1, v8 (&pk)[2][2]) {
+        if (ABL & W64_ABL_NOPACK) {   // the raw bits of four fp32 registers stand for the eight 16-bit probabilities: no instruction
+          pk[0][0] = __builtin_bit_cast(v8, __builtin_shufflevector(s0, s0, 0, 1, 2, 3));
+          pk[0][1] = __builtin_bit_cast(v8, __builtin_shufflevector(s0, s0, 8, 9, 10, 11));
+          pk[1][0] = __builtin_bit_cast(v8, __builtin_shufflevector(s1, s1, 0, 1, 2, 3));
+          pk[1][1] = __builtin_bit_cast(v8, __builtin_shufflevector(s1, s1, 8, 9, 10, 11));
+          return;
+        }
         pk[0][0] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 0, 1, 2, 3, 4, 5, 6, 7), v8);
         pk[0][1] = __builtin_convertvector(__builtin_shufflevector(s0, s0, 8, 9, 10, 11, 12, 13, 14, 15), v8);
         pk[1][0] = __builtin_convertvector(__builtin_shufflevector(s1, s1, 0, 1, 2, 3, 4, 5, 6, 7), v8);
@@ -450,6 +466,16 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       };
       // exponentials in place, the 16-bit probabilities, and four partial sums of the TILE's row sum
       auto exp_sum = [&](f32x16& s0, f32x16& s1, float (&ts)[4], v8 (&pk)[2][2]) {
+        if (ABL & (W64_ABL_NOEXP | W64_ABL_NOSUM)) {   // ablations: the same walk with the exponentials and / or the sums left out
+          ts[0] = ts[1] = ts[2] = ts[3] = 1.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (!(ABL & W64_ABL_NOEXP)) { s0[r] = fast_exp2(s0[r]); s1[r] = fast_exp2(s1[r]); }
+            if (!(ABL & W64_ABL_NOSUM)) { ts[r & 1] += s0[r]; ts[2 + (r & 1)] += s1[r]; }
+          }
+          pack(s0, s1, pk);
+          return;
+        }
         s0[0] = fast_exp2(s0[0]); s0[1] = fast_exp2(s0[1]); s1[0] = fast_exp2(s1[0]); s1[1] = fast_exp2(s1[1]);
         ts[0] = s0[0]; ts[1] = s0[1]; ts[2] = s1[0]; ts[3] = s1[1];
 #pragma unroll
@@ -479,7 +505,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       exp_sum(sa0, sa1, tsA, pkA);
       exp_sum(sb0, sb1, tsB, pkB);
       const float big = max3(max3(tsA[0], tsA[1], tsA[2]), max3(tsB[0], tsB[1], tsB[2]), max3(tsA[3], tsB[3], tsB[3]));
-      if (t == 0 || __any(!(big <= 2048.f))) {
+      if (t == 0 || (!(ABL & (W64_ABL_NOEXP | W64_ABL_NOSUM)) && __any(!(big <= 2048.f)))) {
         qk_tile(Kb, sa0, sa1, sb0, sb1);
         if (valid < KVB) { mask(sa0, sa1); mask(sb0, sb1); }
         redo(A, sa0, sa1, tsA, pkA);
@@ -504,7 +530,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     // (vector memory operations retire in issue order and nothing else was issued after them)
     if (RING == 3 && t + 2 < NTILES) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!(ABL & W64_ABL_NOBAR)) __syncthreads();
     cur = (RING == 3) ? (cur == 2 ? 0 : cur + 1) : (cur ^ 1);
   }
   }
@@ -564,7 +590,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   finish(Bk, qrowB, 32);
 }
 
-template <typename T, bool FOLD, int NW = 4, bool QS = false>
+template <typename T, bool FOLD, int NW = 4, bool QS = false, int ABL = 0>
 hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   AttnKParams p = p0;
   constexpr int QB = NW * 64;
@@ -595,13 +621,13 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
     if (!attr_set[dev]) {
-      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, QS>,
+      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, QS, ABL>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
       if (ea != hipSuccess) return ea;
       attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, QS>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
+  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, QS, ABL>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || k <= 1) return e;
   return ir_launch_shared_attn_combine(p, std::is_same<T, __bf16>::value ? 1 : 0, QB, rem, s);
@@ -628,3 +654,36 @@ hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStr
   if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true>(p, s) : launch<_Float16, true>(p, s);
   return dtype == 1 ? launch<__bf16, false>(p, s) : launch<_Float16, false>(p, s);
 }
+
+#ifdef IR_ABLATIONS
+// energy / timing ablations of the QS form (bf16 / fp16, 8 waves, with or without the fold): tuning values 20 + index
+template <typename T, int ABL>
+static hipError_t launch_abl(const AttnKParams& p, hipStream_t s) {
+  return p.aa != nullptr ? launch<T, true, 8, true, ABL>(p, s) : launch<T, false, 8, true, ABL>(p, s);
+}
+// ladder (each row ADDS one class to the row before): 63 matrix skeleton | 55 + exponentials | 39 + row sums | 7 + conversions |
+// 3 + Q re-reads | (0 = the product kernel: + DMA + barrier); leave-one-out from the product kernel: 8 exponentials, 16 row sums,
+// 32 conversions, 4 Q re-reads (3 = DMA + barrier is the ladder's last row)
+static const int kW64AblMasks[] = {63, 55, 39, 7, 3, 8, 16, 32, 4};
+int ir_w64_abl_count(void) { return (int)(sizeof(kW64AblMasks) / sizeof(kW64AblMasks[0])); }
+int ir_w64_abl_mask(int index) { return index >= 0 && index < ir_w64_abl_count() ? kW64AblMasks[index] : -1; }
+template <typename T>
+static hipError_t launch_abl_t(const AttnKParams& p, int index, hipStream_t s) {
+  switch (index) {
+    case 0: return launch_abl<T, 63>(p, s);
+    case 1: return launch_abl<T, 55>(p, s);
+    case 2: return launch_abl<T, 39>(p, s);
+    case 3: return launch_abl<T, 7>(p, s);
+    case 4: return launch_abl<T, 3>(p, s);
+    case 5: return launch_abl<T, 8>(p, s);
+    case 6: return launch_abl<T, 16>(p, s);
+    case 7: return launch_abl<T, 32>(p, s);
+    case 8: return launch_abl<T, 4>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+hipError_t ir_launch_shared_attn_fwd_w64_abl(const AttnKParams& p, int dtype, int index, hipStream_t s) {
+  if (!p.q_prescaled) return hipErrorInvalidValue;
+  return dtype == 1 ? launch_abl_t<__bf16>(p, index, s) : launch_abl_t<_Float16>(p, index, s);
+}
+#endif

@@ -658,15 +658,14 @@ _TUNING = int(os.environ.get("IR_ATTN_VARIANT", "0") or 0)
 
 
 def tuning_supports_prescaled_q() -> bool:
-    """``IR_FLAG_Q_PRESCALED`` is implemented by the default dispatch and by the kernels it picks from (tuning 0, 11, 13,
-    17, 18); under any other A/B ``tuning`` the processors keep the plain q (the C ABI rejects the combination)"""
-    return _TUNING in (0, 11, 13, 17, 18)
+    """``IR_FLAG_Q_PRESCALED`` is implemented by the default dispatch and by the kernels it picks from (tuning 0, 11, 13, 18;
+    the development build's ablations 20-28 take the flag explicitly); under any other A/B ``tuning`` the processors keep the plain q (the C ABI rejects the combination)"""
+    return _TUNING in (0, 11, 13, 18)
 
 
 def set_attn_variant(variant: int) -> int:
     """tuning hook for benchmarks / A-B tests: the value goes into the per-call ``tuning`` field of the C ABI's
-    argument block (``IR_TUNE_*`` in include/instantrestore_hip.h; 0 = default dispatch, 16 = one-wave-per-SIMD
-    pipelined kernel, 13 / 12 = 64-row kernel in 8- / 4-wave workgroups, 10 / 14 = pipelined 32-row kernel, 11 = its
+    argument block (``IR_TUNE_*`` in include/instantrestore_hip.h; 0 = default dispatch, 13 / 12 = 64-row kernel in 8- / 4-wave workgroups, 10 / 14 = pipelined 32-row kernel, 11 = its
     pre-scaled-Q form).  ``IR_ATTN_VARIANT=<n>`` in the environment sets the initial value.  Returns the previous one.
     The C library itself holds no such state."""
     global _TUNING

@@ -52,7 +52,8 @@ def test_one_rank_rccl_communicator_carries_control_plane_and_scatter_gather():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", SCRIPT, REPO], capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    res = json.loads(r.stdout.strip().splitlines()[-1])
+    # (librccl prints "Librccl path : ..." through C stdio, flushed at exit: the JSON line is not necessarily the last one)
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["backend"] == "nccl" and res["world"] == 1 and res["init"]["ok"]
     assert res["max"] == 3.5
     assert res["shape"] == [3, 64, 64, 3] and res["dtype"] == "torch.uint8"

@@ -19,6 +19,8 @@ struct AttnKParams {
   void* out;
   float* lse;
   void* probs;      // attn_probs kernel only
+  const int32_t* valid;   // ABI v8 (ir_shared_attn_args.valid_refs): references n >= valid[b] are all-zero in k_ref / v_ref: the default
+                          // kernels (64-row, pipelined 32-row) close them analytically instead of walking their tiles; nullptr: walk all
   int64_t q_sb, q_sl, q_sh;
   int64_t ks_sb, ks_sl, ks_sh;
   int64_t vs_sb, vs_sl, vs_sh;

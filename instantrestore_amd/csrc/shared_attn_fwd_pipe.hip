@@ -72,12 +72,20 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
   }
   const int lin = xcd * p.sk_ix + item_local;
   if (item_local >= p.sk_ix || lin >= p.sk_items) return;  // padding of the last XCD chunk
-  const int tile_begin = (int)(((long)p.ntiles * piece) / npiece);
-  const int tile_end = (int)(((long)p.ntiles * (piece + 1)) / npiece);
   const int bh = lin / p.nqb;
   const int qb = lin - bh * p.nqb;
   const int b = bh / p.H;
   const int h = bh - b * p.H;
+  // ABI v8 (valid_refs): the all-zero suffix of the reference list (n >= valid[b]) is not walked; the piece that owns the end
+  // of the range adds it in closed form before the epilogue (shared_attn_fwd_w64.hip has the derivation)
+  int nref = p.N;
+  if (p.valid != nullptr) {
+    const int vb = p.valid[b];
+    nref = vb < 0 ? 0 : (vb < p.N ? vb : p.N);
+  }
+  const int ntiles_b = p.tiles_self + nref * p.tiles_ref;
+  const int tile_begin = (int)(((long)ntiles_b * piece) / npiece);
+  const int tile_end = (int)(((long)ntiles_b * (piece + 1)) / npiece);
 
   const int qrow = qb * QB + wid * 32 + lq;
   const int qrow_c = qrow < p.Lq ? qrow : p.Lq - 1;
@@ -128,7 +136,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
   constexpr bool DMA_FLAG = (ABL & (64 | 128 | 256)) != 0;
   constexpr bool DMA_ASM = (ABL & (128 | 256)) != 0;  // DMA issued from inline asm, waited for by hand
   i32x4 krw = {0, 0, 0, 0}, vrw = {0, 0, 0, 0};
-  const int nseg = p.include_self + p.N;
+  const int nseg = p.include_self + nref;
   __amdgpu_buffer_rsrc_t krs, vrs;
   int kstep = 0, vstep = 0, sntile = 0;
   unsigned kvo[CH], vvo[CH];
@@ -568,6 +576,43 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
 
   // ---- epilogue -----------------------------------------------------------------------------
   if (FOLD && ct0 != 0) fold_segment();  // a piece that stops inside a segment folds what it has
+  if (nref < p.N && piece == npiece - 1) {
+    // zero-filled references in closed form (ABI v8): (N - nref) * Lr keys that all score exactly 0 and carry a zero value
+    // row (with the fold: the AdaIN shift b).  The reference moves up to 0 if it was below; everything accumulated is
+    // rescaled once; the row sum takes cnt * 2^(-m) and the folded total that weight times the suffix's summed shifts.
+    const float cnt = (float)(p.N - nref) * (float)p.Lr;
+    if (!PRESC && m_run == -INFINITY) m_run = 0.f;             // no tile walked at all
+    const float e = PRESC ? -m_run : -m_run * c2;
+    const float up = max3(e, 0.f, 0.f);
+    const float alpha = fast_exp2(-up);
+    m_run += PRESC ? up : up / c2;
+    const float pz = fast_exp2(e - up) * cnt;
+    if (FOLD) {
+      l_tot = l_tot * alpha + pz;
+      m_ot = m_run;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0;
+        for (int n = nref; n < p.N; ++n) {
+          const int64_t ao = ((int64_t)(b * p.N + n) * p.H + h) * 64 + 4 * hi;
+          bs0 += *(const f32x4*)(p.ab + ao + 8 * g4);
+          bs1 += *(const f32x4*)(p.ab + ao + 32 + 8 * g4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g4 + i;
+          ot_lds[r * NT] = __builtin_fmaf(pz, bs0[i], ot_lds[r * NT] * alpha);
+          ot_lds[(16 + r) * NT] = __builtin_fmaf(pz, bs1[i], ot_lds[(16 + r) * NT] * alpha);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      la *= alpha;
+      lb *= alpha;
+      if (hi == 0) la[0] += pz;                                // the two lanes of a row add their partial sums below
+    }
+  }
   float l_fin;
   if (FOLD) {
     l_fin = l_tot;  // everything is folded and m_ot == m_run

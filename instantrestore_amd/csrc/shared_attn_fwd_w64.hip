@@ -88,11 +88,21 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   }
   const int lin = xcd * p.sk_ix + item_local;
   if (item_local >= p.sk_ix || lin >= p.sk_items) return;
-  const int tile_begin = (int)(((long)p.ntiles * piece) / npiece);
-  const int tile_end = (int)(((long)p.ntiles * (piece + 1)) / npiece);
-  const int NTILES = tile_end - tile_begin;
   const int bh = lin / p.nqb, qb = lin - bh * p.nqb;
   const int b = bh / p.H, h = bh - b * p.H;
+  // ABI v8 (valid_refs): references n >= valid[b] are all-zero (ir_zero_invalid_refs; pix2pix_turbo.py:269-273).  Every score
+  // of a zero key is exactly 0 and every value row is 0 (or the AdaIN shift), so that SUFFIX of the segment list is not
+  // walked: this item's K/V range ends after reference nref - 1 and the piece that owns the end of the range adds the
+  // suffix in closed form before the epilogue (zero_suffix below).  Same result as walking it: zeroed, not masked.
+  int nref = p.N;
+  if (p.valid != nullptr) {
+    const int vb = p.valid[b];
+    nref = vb < 0 ? 0 : (vb < p.N ? vb : p.N);
+  }
+  const int ntiles_b = p.tiles_self + nref * p.tiles_ref;
+  const int tile_begin = (int)(((long)ntiles_b * piece) / npiece);
+  const int tile_end = (int)(((long)ntiles_b * (piece + 1)) / npiece);
+  const int NTILES = tile_end - tile_begin;
 
   // ---- Q fragments of both row blocks -----------------------------------------------------------
   const int qrowA = qb * QB + wid * 64 + lq, qrowB = qrowA + 32;
@@ -124,7 +134,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   int srow[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) srow[c] = (tid >> 3) + c * (NT / 8);
-  const int nseg = p.include_self + p.N;
+  const int nseg = p.include_self + nref;
   i32x4 krw = {0, 0, 0, 0}, vrw = {0, 0, 0, 0};
   int kstep = 0, vstep = 0, sntile = 0, seg = 0, t0 = 0;
   unsigned kvo[CH], vvo[CH];
@@ -537,6 +547,51 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 
   // ---- epilogue (per row block) ---------------------------------------------------------------------
   if (FOLD && ct0 != 0) fold_boundary(cseg, false);  // a piece that stops inside a segment closes what it has
+  // Zero-filled references in closed form (ABI v8): the nzero * Lr keys of the suffix all score exactly 0.  With the running
+  // reference m (exponent domain) a zero score weighs 2^(-m): the reference first moves up to 0 if it was below (exact max,
+  // once per launch), then the row sum takes nzero * Lr * 2^(-m) and - with the AdaIN fold - the output takes that weight
+  // times the sum of the suffix's shifts b (a * 0 + b per key; the accumulators are the true total here: the last boundary
+  // closed the ratio frame with a_next = 1).  Without the fold the value rows are 0 and only the row sum moves.
+  if (nref < p.N && piece == npiece - 1) {
+    const KArgs c = cold();
+    const float cnt = (float)(c->N - nref) * (float)c->Lr;
+    auto zero_suffix = [&](RowBlock& R) -> float {
+      if (!QS && R.m_run == -INFINITY) R.m_run = 0.f;          // no tile walked at all: the reference starts at the zero score
+      const float e = QS ? -R.m_run : -R.m_run * c2;           // exponent of a zero score relative to the reference
+      const float up = max3(e, 0.f, 0.f);
+      const float alpha = fast_exp2(-up);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { R.o0[r] *= alpha; R.o1[r] *= alpha; }
+      R.la *= alpha;
+      R.lb *= alpha;
+      if (FOLD) R.l_done *= alpha;
+      R.m_run += QS ? up : up / c2;
+      const float pz = fast_exp2(e - up) * cnt;
+      if (FOLD) R.l_done += pz;
+      else if (hi == 0) R.la[0] += pz;                         // the two lanes of a row add their partial sums in finish()
+      return pz;
+    };
+    const float pzA = zero_suffix(A), pzB = zero_suffix(Bk);
+    if (FOLD) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = bs0;
+        for (int n = nref; n < c->N; ++n) {
+          const int64_t ao = ((int64_t)(b * c->N + n) * c->H + h) * 64 + 4 * hi;
+          bs0 += *(const f32x4*)(c->ab + ao + 8 * g4);
+          bs1 += *(const f32x4*)(c->ab + ao + 32 + 8 * g4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int r = 4 * g4 + i;
+          A.o0[r] = __builtin_fmaf(pzA, bs0[i], A.o0[r]);
+          Bk.o0[r] = __builtin_fmaf(pzB, bs0[i], Bk.o0[r]);
+          A.o1[r] = __builtin_fmaf(pzA, bs1[i], A.o1[r]);
+          Bk.o1[r] = __builtin_fmaf(pzB, bs1[i], Bk.o1[r]);
+        }
+      }
+    }
+  }
   auto finish = [&](RowBlock& R, int qrow, int rowoff) {
     float l_fin;
     if (FOLD) {

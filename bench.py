@@ -110,8 +110,9 @@ def _hot_path_step(layers, B, N, ref_early_exit=False, two_streams=False, cached
     fill 256 CUs on their own - overlap with the other UNet's kernels.  Same kernels, same work."""
     from instantrestore_amd.attn_processors import ReferenceCaptureComplete
     if cached_kv is not None:
-        keys, vals, stats = cached_kv if len(cached_kv) == 3 else (cached_kv[0], cached_kv[1], None)
-        return [ly["main_attn"](ly["h_main"], ref_keys=keys, ref_values=vals, ref_stats=stats) for ly in layers]
+        keys, vals, stats = (cached_kv[0], cached_kv[1], cached_kv[2] if len(cached_kv) > 2 else None)
+        rvalid = cached_kv[3] if len(cached_kv) > 3 else None    # int32 (B,): references n >= valid[b] are zero-filled (ABI v8)
+        return [ly["main_attn"](ly["h_main"], ref_keys=keys, ref_values=vals, ref_stats=stats, ref_valid=rvalid) for ly in layers]
     cur = torch.cuda.current_stream()
     ref_stream = cur
     if two_streams:
@@ -592,6 +593,35 @@ def extra_graph(layers, B, N, steps):
         detail.update({"mismatching": bad,
                        "eager_repeats_itself": all(torch.equal(a, b) for a, b in zip([t for part in again for t in part], ref))})
     return sec, not bad, detail
+
+
+def extra_ragged_valid(layers, B, N, keys, vals, cst, sec_all_valid, train_input, steps, dev):
+    """Zero-filled references in closed form (ABI v8 ``valid_refs``): the nine shared layers on cached K/V whose references
+    ``n >= valid`` were zero-filled like pix2pix_turbo.py:269-273 does (``inference/test.py:81`` passes the CHECKPOINT's
+    ``max_conditioning_images``: 4 of the 8 references of the cfg-4 case).  Timed twice per valid count: the kernels told the
+    counts (``ref_valid``: the zero suffix is not walked) and not told (they walk the zero tiles like any other) - same output
+    (tests/test_gpu_valid_refs.py).  ``expected_ratio`` = (t + valid) / (t + N): attention time in proportion to the segments."""
+    from instantrestore_amd import ops as _o
+    t = 1 if train_input else 0
+    rows = []
+    for nv in sorted({max(N // 2, 1), max(N // 4, 0), N - 1}):
+        if nv >= N:
+            continue
+        valid = torch.full((B,), nv, dtype=torch.int32, device=dev)
+        kz, vz = [k.clone() for k in keys], [v.clone() for v in vals]
+        for k, v in zip(kz, vz):
+            _o.zero_invalid_refs(k, v, valid, heads=k.shape[-1] // _o.HEAD_DIM)
+        st = None
+        if cst is not None:      # cached content statistics: an all-zero V has statistics (0, 0)
+            keep = (torch.arange(N, device=dev)[None, :] < valid[:, None]).float()[:, :, None, None]
+            st = [None if c is None else ((c[0] * keep).contiguous(), (c[1] * keep).contiguous()) for c in cst]
+        sec_told = _time_steps(lambda: hot_path_step(layers, B, N, cached_kv=(kz, vz, st, valid)), steps)
+        sec_walk = _time_steps(lambda: hot_path_step(layers, B, N, cached_kv=(kz, vz, st)), steps)
+        rows.append({"valid": nv, "of": N, "ms_per_step_counts_passed": round(sec_told * 1e3, 4), "ms_per_step_zero_tiles_walked": round(sec_walk * 1e3, 4),
+                     "ratio_to_all_valid": round(sec_told / sec_all_valid, 3), "expected_ratio_attention_only": round((t + nv) / (t + N), 3)})
+        del kz, vz
+    return {"all_valid_ms_per_step": round(sec_all_valid * 1e3, 4), "rows": rows,
+            "note": "nine shared layers on cached K/V (the kv_cached leg); the projections and the self segment do not shrink with the valid count"}
 
 
 def extra_probs_dump(layers, B, N, train_input, dtype, dev):
@@ -1082,6 +1112,10 @@ def main():
                 extras["kv_cached"] = {"images_per_s": round(B / secc, 2), "ms_per_step": round(secc * 1e3, 4),
                                        "note": "reference K/V served from the per-identity cache (SURVEY 8f rank 2): only the nine "
                                                "shared layers run; valid when the references of an identity repeat across frames"}
+                try:
+                    extras["ragged_valid"] = extra_ragged_valid(layers, B, N, keys, vals, cst if use_adain else None, secc, train_input, args.steps, dev)
+                except Exception as e:
+                    extras["ragged_valid"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 del keys, vals, cst
                 try:
                     pstep = cap.replay if cap is not None else (lambda: hot_path_step(layers, B, N, args.ref_early_exit, bool(args.two_streams)))

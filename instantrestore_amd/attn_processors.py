@@ -393,7 +393,10 @@ class SharedAttnProcessor(nn.Module):
         self.train_input = train_input
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                ref_keys=None, ref_values=None, ref_events=None, ref_stats=None):
+                ref_keys=None, ref_values=None, ref_events=None, ref_stats=None, ref_valid=None):
+        """``ref_valid`` (optional, round 5): int32 ``(B,)`` device tensor from the harvest (``kv_harvest`` ``with_valid``) when
+        it zero-filled references ``n >= valid[b]`` (pix2pix_turbo.py:269-273): the kernel then closes those all-zero segments
+        analytically instead of walking them (ABI v8 ``valid_refs``).  Same output; the tokens keep their exp(0) weight."""
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         shared = self.self_attn_idx is not None and ref_keys is not None and ref_values is not None
         # the GEMM's statistics tail (style partials of this layer's own V) only pays when the content statistics arrive
@@ -446,6 +449,8 @@ class SharedAttnProcessor(nn.Module):
 
         want_probs = bool(self.save_self_attentions)
         kw = {"q_prescaled": True} if presc else {}
+        if shared and ref_valid is not None:
+            kw["valid_refs"] = ref_valid
         res = _ops.shared_attention(query, key, value, ref_k, ref_v, heads=attn.heads, scale=attn.scale,
                                     include_self=include_self, adain=affine, return_lse=want_probs, **kw)
         if want_probs:

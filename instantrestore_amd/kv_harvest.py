@@ -21,7 +21,7 @@ from . import ops as _ops
 
 
 def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int],
-                         reset: bool = True, with_events: bool = False, with_stats: bool = False):
+                         reset: bool = True, with_events: bool = False, with_stats: bool = False, with_valid: bool = False):
     """``(keys, values)`` - or ``(keys, values, events)`` with ``with_events``: one HIP event per layer,
     recorded by the capturing processor right after its K/V projections when ``record_events`` was set on
     it (see :func:`enable_stream_overlap`); hand them to the main UNet as
@@ -33,7 +33,11 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
     fp32 ``(B, N, H, 64)`` - the CONTENT statistics of AdaIN (attn_processors.py:9-10), stashed by the capturing processors
     (:func:`enable_ref_stats`) or computed here when they were not; pass it on as ``'ref_stats'`` and the shared layers
     read only their own V (``ir_adain_stats_cached``).  References zero-filled below get the statistics of an all-zero
-    V, (0, 0): exactly what the uncached path computes from the zeroed tensor (the ``b == mean(V_self)`` quirk)."""
+    V, (0, 0): exactly what the uncached path computes from the zeroed tensor (the ``b == mean(V_self)`` quirk).
+
+    ``with_valid`` (round 5) appends ``valid``: the int32 ``(B,)`` device tensor of valid counts when some reference was
+    zero-filled here, else ``None`` - hand it on as ``'ref_valid'`` and the shared layers close the zeroed segments in closed
+    form instead of walking them (ABI v8 ``valid_refs``; same output)."""
     procs = [p for p in original_unet.attn_processors.values() if type(p) in [_ap.AttnProcessor]]
     if not procs:
         raise RuntimeError("no AttnProcessor on this UNet: call register_attention_processor_kv_unet first")
@@ -62,6 +66,7 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
                 m, sd = _ops.token_stats(v, heads=heads)
             stats.append(None if m is None else (m.reshape(-1, n_refs, *m.shape[-2:]), sd.reshape(-1, n_refs, *sd.shape[-2:])))
     valid = torch.as_tensor(valid_indices)
+    valid_out = None
     if bool((valid < n_refs).any()):
         if keys[0].is_cuda:
             # The zero fill runs on the CURRENT stream and rewrites the stashes in place.  The reference does it after
@@ -77,10 +82,12 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
                 v.record_stream(cur)
         for k, v in zip(keys, values):
             _ops.zero_invalid_refs(k, v, valid, heads=k.shape[-1] // _ops.HEAD_DIM)
+        if keys[0].is_cuda:
+            valid_out = valid.to(device=keys[0].device, dtype=torch.int32).contiguous()
         if with_stats and keys[0].is_cuda:
             # the zero fill invalidates the cached statistics of the zeroed references: an all-zero V has mean 0, std 0
             keep = (torch.arange(n_refs)[None, :] < valid.reshape(-1, 1)).to(device=keys[0].device, dtype=torch.float32)[:, :, None, None]
-            valid_dev = valid.to(device=keys[0].device, dtype=torch.int32).contiguous()
+            valid_dev = valid_out
             for st in stats:
                 if hasattr(st, "finished"):
                     st.valid = valid_dev          # the affine kernel (and finished()) count these references as all-zero
@@ -97,8 +104,10 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
             ev = torch.cuda.Event()
             ev.record()
             events = [ev] * len(keys)
-        return (keys, values, events, stats) if with_stats else (keys, values, events)
-    return (keys, values, stats) if with_stats else (keys, values)
+        res = (keys, values, events, stats) if with_stats else (keys, values, events)
+    else:
+        res = (keys, values, stats) if with_stats else (keys, values)
+    return res + (valid_out,) if with_valid else res
 
 
 def finished_stats(stats):
@@ -128,7 +137,7 @@ def enable_stream_overlap(original_unet, enabled: bool = True) -> None:
 
 def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, timestep, encoder_hidden_states,
                                  n_refs: int, valid_indices: Sequence[int], early_exit: bool = False,
-                                 with_stats: bool = False):
+                                 with_stats: bool = False, with_valid: bool = False):
     """Run the frozen reference UNet on the (already encoded and noised) reference latents
     ``(B*N, 4, S, S)`` and harvest.  VAE encode/decode, the scheduler and the caption encoder
     around it (pix2pix_turbo.py:244-257, 277-278) are stock PyTorch and out of scope.
@@ -148,7 +157,7 @@ def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, times
     try:
         if not early_exit:
             original_unet(model_input, timestep, encoder_hidden_states=encoder_hidden_states)
-            return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats)
+            return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats, with_valid=with_valid)
         for p in procs:                          # whichever capturing layer runs last stops the forward
             p.reset()
             p.stop_after_capture = procs
@@ -161,7 +170,7 @@ def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, times
         finally:
             for p in procs:
                 p.stop_after_capture = None
-        return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats)
+        return harvest_reference_kv(original_unet, n_refs, valid_indices, with_stats=with_stats, with_valid=with_valid)
     finally:
         for p, flag in zip(procs, saved_stats):
             p.capture_stats = flag

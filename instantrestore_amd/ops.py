@@ -98,7 +98,7 @@ def _ref(t: torch.Tensor, heads: int, name: str) -> torch.Tensor:
 
 
 def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split=True,
-               q_prescaled=False):
+               q_prescaled=False, valid_refs=None):
     a = _lib.SharedAttnArgs()
     a.struct_size = C.sizeof(_lib.SharedAttnArgs)
     a.dtype = _dtype_code(q)
@@ -123,6 +123,10 @@ def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adai
         a.vr_sb, a.vr_sn, a.vr_sl, a.vr_sh = ref_v.stride(0), ref_v.stride(1), ref_v.stride(2), HEAD_DIM
     if adain is not None:
         a.adain_a, a.adain_b = adain[0].data_ptr(), adain[1].data_ptr()
+    if valid_refs is not None and ref_k is not None:
+        if valid_refs.dtype != torch.int32 or valid_refs.device != q.device or valid_refs.numel() != q.shape[0] or not valid_refs.is_contiguous():
+            raise ValueError(f"valid_refs must be a contiguous int32 ({q.shape[0]},) tensor on {q.device}")
+        a.valid_refs = valid_refs.data_ptr()
     if out is not None:
         a.out = out.data_ptr()
         a.o_sb, a.o_sl, a.o_sh = out.stride(0), out.stride(1), HEAD_DIM
@@ -190,7 +194,7 @@ def _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain):
 def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
                      include_self: bool = True, adain: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                      return_lse: bool = False, split: bool = True, q_prescaled: bool = False,
-                     out_dtype: Optional[torch.dtype] = None):
+                     out_dtype: Optional[torch.dtype] = None, valid_refs: Optional[torch.Tensor] = None):
     """Fused extended self-attention (``ir_shared_attn_fwd``).
 
     Returns ``out`` (B, Lq, H*64) in q's dtype [and ``lse`` (B, H, Lq) fp32].  ``adain`` is the
@@ -198,13 +202,17 @@ def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, s
     kernel's V staging.  ``q_prescaled``: ``q`` already holds ``Q * scale * log2(e)`` (``IR_FLAG_Q_PRESCALED``: the
     fused q/k/v projection folds the factor into its weights; ``scale`` stays the reference's ``attn.scale``).
     ``out_dtype=torch.float32`` returns the result before its rounding to 16 bit (``IR_FLAG_OUT_F32``, parity tests).
+    ``valid_refs`` (ABI v8): int32 ``(B,)`` on the device - a PROMISE that references ``n >= valid_refs[b]`` are all-zero in
+    ``ref_k`` and ``ref_v`` (``zero_invalid_refs``; pix2pix_turbo.py:269-273).  The kernels then close that suffix of the reference
+    list analytically (every score exactly 0, every value row 0 or the AdaIN shift) instead of walking its tiles: same result,
+    time proportional to the valid segments.  Zeroed, not masked: the tokens keep their exp(0) weight.
     """
     q, k_self, v_self, ref_k, ref_v = _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain)
     if out_dtype not in (None, q.dtype, torch.float32):
         raise TypeError("out_dtype must be the compute dtype or torch.float32")
     out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=out_dtype or q.dtype, device=q.device)
     lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if return_lse else None
-    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split, q_prescaled)
+    args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split, q_prescaled, valid_refs)
     sink = EVENT_SINK
     if sink is not None and sink[0](q, ref_k, adain):   # bench.py: HIP events around chosen launches, in situ
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,0 +1,142 @@
+"""Zero-filled references in closed form (ABI v8 ``valid_refs``).
+
+``Pix2Pix_Turbo.get_conditioning_keys_values`` zero-fills the references ``n >= valid_indices[b]`` in place
+(pix2pix_turbo.py:269-273): zeroed, NOT masked - their keys score exactly 0 and keep an exp(0) softmax weight, their value
+rows are 0 (with AdaIN: the style mean).  When the caller passes the valid counts, the default kernels do not walk that suffix
+of the reference list: row sum and output take its contribution analytically.  Held to: the float64 oracle evaluated on the
+ZERO-FILLED tensors (the reference's own semantics) within the tolerance of tests/test_gpu_parity.py, and to the same call
+without ``valid_refs`` (which walks the zero tiles) within twice that tolerance.  SURVEY 8d: ``inference/test.py:81`` passes
+``max_conditioning_images`` of the CHECKPOINT as valid count - 4 of 8 in the cfg-4 stress case."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import shared_attn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from instantrestore_amd import ops as _ops
+    _ops._lib.lib()
+    return _ops
+
+
+def _np64(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+def _case(B, H, L, N, Lr, dtype, seed, scale_q=1.0):
+    g = torch.Generator().manual_seed(seed)
+    C = H * 64
+    q = (torch.randn(B, L, C, generator=g) * scale_q).to(dtype)
+    k, v = torch.randn(B, L, C, generator=g).to(dtype), (torch.randn(B, L, C, generator=g) * 0.8 + 0.3).to(dtype)
+    rk = torch.randn(B, N, Lr, C, generator=g).to(dtype)
+    rv = (torch.randn(B, N, Lr, C, generator=g) * 1.3 - 0.2).to(dtype)
+    return q, k, v, rk, rv
+
+
+def _run(ops, q, k, v, rk, rv, valid, H, inc, adain, variant=0, pass_valid=True):
+    rk, rv = rk.clone().cuda(), rv.clone().cuda()
+    vd = torch.tensor(valid, dtype=torch.int32, device="cuda")
+    ops.zero_invalid_refs(rk, rv, vd, heads=H)
+    qd, kd, vvd = q.cuda(), k.cuda(), v.cuda()
+    aff = ops.adain_stats(vvd, rv, heads=H) if adain else None
+    ops.set_attn_variant(variant)
+    try:
+        out, lse = ops.shared_attention(qd, kd, vvd, rk, rv, heads=H, scale=0.125, include_self=inc, adain=aff, return_lse=True,
+                                        valid_refs=vd if pass_valid else None)
+    finally:
+        ops.set_attn_variant(0)
+    return out, lse, rk, rv
+
+
+SMALL = [
+    # B, H, L, N, Lr, include_self, valid
+    (3, 2, 256, 4, 256, True, [4, 2, 0]),        # 16x16-token class: all valid / half / none (self segment only)
+    (3, 2, 256, 4, 256, False, [1, 3, 0]),       # no self segment: valid 0 = ONLY zero keys (uniform weights over nothing but zeros)
+    (2, 1, 1024, 4, 1024, True, [3, 1]),         # 32x32-token class
+    (2, 3, 200, 5, 72, True, [2, 5]),            # ragged tiles, partial query block
+    (9, 2, 1024, 4, 1024, True, [4, 3, 2, 1, 0, 1, 2, 3, 4]),   # remainder split of the item grid with per-item K/V ranges
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("adain", [False, True], ids=["plain", "adain"])
+@pytest.mark.parametrize("case", SMALL, ids=[f"B{c[0]}H{c[1]}L{c[2]}N{c[3]}Lr{c[4]}s{int(c[5])}" for c in SMALL])
+def test_closed_form_matches_the_oracle_on_zero_filled_references(ops, case, adain, dtype):
+    B, H, L, N, Lr, inc, valid = case
+    q, k, v, rk, rv = _case(B, H, L, N, Lr, dtype, seed=31 + L + N)
+    out, lse, rkz, rvz = _run(ops, q, k, v, rk, rv, valid, H, inc, adain)
+    for b in range(B):
+        assert float(rkz[b, valid[b]:].abs().max() if valid[b] < N else 0.0) == 0.0
+    ref, p_ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rkz), _np64(rvz), H, 0.125, adain, inc, return_probs=True)
+    got = _np64(out)
+    assert np.isfinite(got).all()
+    bound = TOL[dtype] * max(1.0, np.abs(ref).max())
+    assert np.abs(got - ref).max() <= bound, (np.abs(got - ref).max(), bound)
+    walked, lse_w, _, _ = _run(ops, q, k, v, rk, rv, valid, H, inc, adain, pass_valid=False)
+    assert np.abs(got - _np64(walked)).max() <= 2 * bound
+    # the LSE carries the zero keys too: logsumexp over ALL columns of the zero-filled problem
+    assert float((lse - lse_w).abs().max()) <= 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("adain", [False, True], ids=["plain", "adain"])
+def test_cfg4_top_layer_four_of_eight_references_valid(ops, adain, dtype):
+    """the cfg-4 stress shape (8 references, 64x64 tokens, Lkv = 36 864) with the checkpoint's 4 as valid count: the 64-row kernel;
+    sampled rows against the oracle"""
+    B, H, L, N = 2, 2, 4096, 8
+    q, k, v, rk, rv = _case(B, H, L, N, L, dtype, seed=77)
+    valid = [4, 6]
+    out, lse, rkz, rvz = _run(ops, q, k, v, rk, rv, valid, H, True, adain)
+    rows = np.array(sorted(set(np.random.default_rng(3).integers(0, L, 96).tolist() + [0, 63, 64, L - 1])))
+    ref = O.shared_attention_np(_np64(q)[:, rows], _np64(k), _np64(v), _np64(rkz), _np64(rvz), H, 0.125, adain, True)
+    got = _np64(out)[:, rows]
+    bound = TOL[dtype] * max(1.0, np.abs(ref).max())
+    assert np.abs(got - ref).max() <= bound, (np.abs(got - ref).max(), bound)
+    walked, _, _, _ = _run(ops, q, k, v, rk, rv, valid, H, True, adain, pass_valid=False)
+    assert np.abs(_np64(out) - _np64(walked)).max() <= 2 * bound
+
+
+def test_reference_far_below_zero_moves_up_to_the_zero_score(ops):
+    """every real score is hugely negative (q ~ -k): the zero keys own the softmax; the closed form must move the running
+    reference up to 0 instead of weighing the zero keys with 2^(+large)"""
+    dtype = torch.bfloat16
+    B, H, L, N = 1, 1, 256, 2
+    g = torch.Generator().manual_seed(5)
+    base = torch.randn(B, L, 64, generator=g)
+    q, k = (base * 3).to(dtype), (-base * 3).to(dtype)
+    v = torch.randn(B, L, 64, generator=g).to(dtype)
+    rk = (-base * 3).reshape(B, 1, L, 64).repeat(1, N, 1, 1).to(dtype)
+    rv = torch.randn(B, N, L, 64, generator=g).to(dtype)
+    for adain in (False, True):
+        out, lse, rkz, rvz = _run(ops, q, k, v, rk, rv, [1], H, True, adain)
+        ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rkz), _np64(rvz), H, 0.125, adain, True)
+        got = _np64(out)
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() <= TOL[dtype] * max(1.0, np.abs(ref).max())
+
+
+def test_processor_takes_the_valid_counts_from_the_harvest(ops):
+    """kv_harvest(with_valid=True) -> cross_attention_kwargs['ref_valid'] -> SharedAttnProcessor: same tokens as the walk"""
+    from face_replace.models.attn_processors import SharedAttnProcessor
+    from instantrestore_amd.attention import Attention
+    torch.manual_seed(9)
+    B, H, L, N = 4, 2, 256, 4
+    C = H * 64
+    attn = Attention(query_dim=C, heads=H, dim_head=64,
+                     processor=SharedAttnProcessor(self_attn_idx=0, use_adain=True, train_input=True)).cuda().to(torch.bfloat16)
+    x = torch.randn(B, L, C, device="cuda", dtype=torch.bfloat16)
+    rk = torch.randn(B, N, L, C, device="cuda", dtype=torch.bfloat16)
+    rv = torch.randn(B, N, L, C, device="cuda", dtype=torch.bfloat16)
+    valid = torch.tensor([4, 2, 1, 3], dtype=torch.int32, device="cuda")
+    ops.zero_invalid_refs(rk, rv, valid, heads=H)
+    with torch.no_grad():
+        a = attn(x, ref_keys=[rk], ref_values=[rv], ref_valid=valid)
+        b = attn(x, ref_keys=[rk], ref_values=[rv])
+    assert float((a.float() - b.float()).abs().max()) <= 2 * 8e-3 * max(1.0, float(b.float().abs().max()))

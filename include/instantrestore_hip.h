@@ -349,7 +349,9 @@ int ir_linear_fwd_scaled(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, 
 #define IR_LIN_AUTO 0           /* what ir_linear_fwd / ir_linear_fwd_scaled pick (ir_linear_kernel_for) */
 #define IR_LIN_X_STATIONARY 1
 #define IR_LIN_TILED_FIRST 2    /* 2: 256x128, 3: 128x128, 4: 128x64, 5: 256x64, 6: 64x128, 7: 128x256, 8: 256x256 (rows x columns of Y per
-                                   workgroup; the last two with 64 x 128 per wave) */
+                                   workgroup; 7 and 8 with 64 x 128 per wave), 9: 128x128 with the contraction split over two wave
+                                   groups of the workgroup (K / 64 even; partial sums meet in LDS in a fixed order: deterministic, but
+                                   not the same fp32 rounding as the single-pass tiles) */
 int ir_linear_fwd_ex(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,
                      int64_t w_ld, const void* bias, void* y, int64_t y_ld, int32_t scale_cols, float col_scale,
                      int32_t kernel, void* stream);

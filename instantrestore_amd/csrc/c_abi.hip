@@ -457,7 +457,7 @@ int ir_linear_kernel_for(int64_t m, int32_t n, int32_t k, int32_t has_bias) {
   // matters: large M.  From profiles/r3_gemm_probe_final.txt: at 131072 rows they lead (K = 320: 122 vs 167 us), at 32768
   // rows the 256x256 tile leads or ties (32768 x 960 x 320: 33 vs 43 us; x 1920 x 640: 100 vs 100; x 640 x 640: 39-46 vs 44-54)
   if (xs && m >= 65536) return IR_LIN_X_STATIONARY;
-  return IR_LIN_TILED_FIRST + ir_linear_tiled_pick(m, n);
+  return IR_LIN_TILED_FIRST + ir_linear_tiled_pick(m, n, k);
 }
 
 static int linear_fwd_impl(int32_t dtype, int32_t x_is_f32, int64_t m, int32_t n, int32_t k, const void* x, int64_t x_ld, const void* w,

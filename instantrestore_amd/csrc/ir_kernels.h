@@ -201,9 +201,10 @@ enum {   // tile shapes (rows x columns of Y per workgroup); values are the `ker
   IR_LIN_TILE_64x128 = 4,    // 2 waves
   IR_LIN_TILE_128x256 = 5,   // 4 waves, 64 x 128 per wave
   IR_LIN_TILE_256x256 = 6,   // 8 waves, 64 x 128 per wave, wave groups one phase apart (matrix phase beside load phase on every SIMD)
-  IR_LIN_TILE_COUNT = 7
+  IR_LIN_TILE_128x128_K2 = 7,   // round 5: 128 x 128 with the contraction split over two 4-wave groups (K / 64 even), fixed-order sum through LDS
+  IR_LIN_TILE_COUNT = 8
 };
 hipError_t ir_launch_linear_tiled(const LinearKParams& p, int dtype, int cfg, hipStream_t s);
-int ir_linear_tiled_pick(int64_t M, int N);
+int ir_linear_tiled_pick(int64_t M, int N, int K);
 bool ir_linear_tiled_cfg_ok(int cfg, int N);
 void ir_host_lanczos_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* kk);

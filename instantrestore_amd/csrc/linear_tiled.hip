@@ -28,23 +28,30 @@ namespace {
 
 constexpr int kTiledPitch = 144;   // staging tile row: 128 B (64 columns of Y) + 16 B pad
 
-template <typename T, int WM, int WN, int MI, int NI, bool XF32, bool ILV>
-__global__ void __launch_bounds__(WM * WN * 64, 2) linear_tiled_kernel(const LinearKParams p) {
+// KW = 2 (round 5): TWO wave groups per workgroup split the contraction - group g multiplies K-steps [g KT/2, (g+1) KT/2) of
+// the SAME tile out of its own pair of LDS stages, the groups meet at the end: group 1 hands its fp32 accumulators over
+// through LDS, group 0 adds them (always k-half 0 + k-half 1: one fixed order, no atomics, nothing through memory) and
+// runs the epilogue.  For shapes whose tile count leaves CUs idle (M = 2048 rows: 160 tiles of 128 x 128 at N = 1280): the K
+// loop of a tile is half as long and every busy CU holds eight waves instead of four.
+template <typename T, int WM, int WN, int MI, int NI, bool XF32, bool ILV, int KW = 1>
+__global__ void __launch_bounds__(WM * WN * KW * 64, KW == 1 ? 2 : 1) linear_tiled_kernel(const LinearKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
   using v4 = typename Tr::v4;
-  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int NW = WM * WN, NT = NW * 64;      // waves / threads of ONE K group
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr int XT = BM * 128, WT = BN * 128, STAGE = XT + WT;
   constexpr int XP = BM / 8 / NW, WP = BN / 8 / NW;    // 1-KiB LDS-DMA pieces per wave and K-step
   constexpr int XU = BM * 8 / NT;                      // fp32 path: 8-element units per thread and K-step
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "pieces must divide over the waves");
   extern __shared__ __attribute__((aligned(16))) unsigned char dsm_tiled[];
-  unsigned char* const smem = dsm_tiled;
+  const int lane = threadIdx.x & 63;
+  const int wid_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int kg = KW == 1 ? 0 : wid_all / NW;     // K group of this wave
+  const int wid = KW == 1 ? wid_all : wid_all - kg * NW;
+  const int tid = wid * 64 + lane;               // thread index inside the group
+  unsigned char* const smem = dsm_tiled + kg * (2 * STAGE);   // the group's own two stages
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wid / WN, wn = wid - wm * WN;
   const int hi = lane >> 5, lq = lane & 31;
 
@@ -57,7 +64,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) linear_tiled_kernel(const Lin
   const int tm = grp * GM + rem % gm, tn = rem / gm;
   const int m0 = tm * BM, n0 = tn * BN;
   const int rows_valid = (p.M - m0) < BM ? (p.M - m0) : BM;
-  const int KT = p.K >> 6;
+  const int KT = (p.K >> 6) / KW;                // K-steps of this group (the launcher picks KW = 2 only for an even count)
+  const int kt0 = kg * KT;                       // ... starting here
 
   // ---- operand streams ---------------------------------------------------------------------------------------------
   const T* const wbase = (const T*)p.w + (int64_t)n0 * p.w_ld;
@@ -93,8 +101,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) linear_tiled_kernel(const Lin
   constexpr int NPIECE = WP + (XF32 ? 0 : XP);
   auto issue_piece = [&](int j, int kt, int slot) {
     unsigned char* const sx = smem + slot * STAGE;
-    if (j < WP) buffer_load_lds16_async(wrs, sx + XT + (wid + j * NW) * 1024, wvo[j] + kt * 128);
-    else if constexpr (!XF32) buffer_load_lds16_async(xrs, sx + (wid + (j - WP) * NW) * 1024, xvo[j - WP] + kt * 128);
+    if (j < WP) buffer_load_lds16_async(wrs, sx + XT + (wid + j * NW) * 1024, wvo[j] + (kt0 + kt) * 128);
+    else if constexpr (!XF32) buffer_load_lds16_async(xrs, sx + (wid + (j - WP) * NW) * 1024, xvo[j - WP] + (kt0 + kt) * 128);
   };
   auto issue_dma = [&](int kt, int slot) {
 #pragma unroll
@@ -109,8 +117,8 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) linear_tiled_kernel(const Lin
     if constexpr (XF32) {
 #pragma unroll
       for (int j = 0; j < XU; ++j) {
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[j][0]) : "v"(xfp[j] + kt * 64) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(xr[j][1]) : "v"(xfp[j] + kt * 64) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[j][0]) : "v"(xfp[j] + (kt0 + kt) * 64) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(xr[j][1]) : "v"(xfp[j] + (kt0 + kt) * 64) : "memory");
       }
     }
   };
@@ -201,6 +209,35 @@ __global__ void __launch_bounds__(WM * WN * 64, 2) linear_tiled_kernel(const Lin
   }
   compute((KT - 1) & 1, -1, 0);
   __syncthreads();                  // every wave is done with the operand stages: they become the output staging tiles
+  if constexpr (KW == 2) {
+    // hand-over of the second K half: wave w of group 1 leaves its MI*NI*16 accumulators, four per lane and slot, in the upper
+    // half of LDS (behind everything the epilogue's staging tiles touch); wave w of group 0 adds them in a fixed order
+    constexpr int HAND_OFF = 2 * STAGE;                  // = group 1's own stages: free since the barrier above
+    static_assert(2 * STAGE >= NW * MI * 32 * kTiledPitch, "epilogue staging must stay below the hand-over area");
+    static_assert(2 * STAGE >= NW * MI * NI * 16 * 64 * 4, "hand-over area");
+    unsigned char* const hand = dsm_tiled + HAND_OFF + wid * (MI * NI * 16 * 64 * 4) + lane * 16;
+    if (kg == 1) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *(f32x4_alias*)(hand + ((mi * NI + ni) * 4 + g) * 1024) = f32x4{acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1], acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]};
+    }
+    __syncthreads();
+    if (kg == 1) return;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o = *(const f32x4_alias*)(hand + ((mi * NI + ni) * 4 + g) * 1024);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[mi][ni][4 * g + i] += o[i];
+        }
+  }
 
   // ---- epilogue: column scale, bias, one rounding, transposed through LDS into whole lines of Y -------------------
   // (64 columns at a time: a wave's LDS operations execute in order, so the tile is reused without a barrier)
@@ -578,25 +615,26 @@ hipError_t launch_pp(const LinearKParams& p0, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename T, int WM, int WN, int MI, int NI, bool XF32, bool ILV>
+template <typename T, int WM, int WN, int MI, int NI, bool XF32, bool ILV, int KW = 1>
 hipError_t launch_cfg(const LinearKParams& p0, hipStream_t s) {
   LinearKParams p = p0;
   p.nsplit = walk_group_rows();
   constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
   constexpr size_t stage = (size_t)(BM + BN) * 128;
   constexpr size_t epi = (size_t)WM * WN * MI * 32 * kTiledPitch;
-  constexpr size_t dyn = 2 * stage > epi ? 2 * stage : epi;
+  constexpr size_t dyn = KW * 2 * stage > epi ? KW * 2 * stage : epi;
+  if (KW == 2 && ((p.K >> 6) & 1)) return hipErrorInvalidValue;   // the two K groups take whole, equal halves
   static bool attr_set[64] = {};   // per instantiation and per device; idempotent
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
   if (!attr_set[dev]) {
-    hipError_t ea = hipFuncSetAttribute((const void*)linear_tiled_kernel<T, WM, WN, MI, NI, XF32, ILV>,
+    hipError_t ea = hipFuncSetAttribute((const void*)linear_tiled_kernel<T, WM, WN, MI, NI, XF32, ILV, KW>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     if (ea != hipSuccess) return ea;
     attr_set[dev] = true;
   }
   const int MT = (p.M + BM - 1) / BM, NTl = p.N / BN;
-  hipLaunchKernelGGL((linear_tiled_kernel<T, WM, WN, MI, NI, XF32, ILV>), dim3((unsigned)(MT * NTl)), dim3(WM * WN * 64), dyn, s, p);
+  hipLaunchKernelGGL((linear_tiled_kernel<T, WM, WN, MI, NI, XF32, ILV, KW>), dim3((unsigned)(MT * NTl)), dim3(WM * WN * KW * 64), dyn, s, p);
   return hipGetLastError();
 }
 
@@ -610,6 +648,7 @@ hipError_t launch_x(const LinearKParams& p, int cfg, hipStream_t s) {
     case IR_LIN_TILE_256x64: return launch_cfg<T, 4, 1, 2, 2, XF32, I>(p, s);
     case IR_LIN_TILE_64x128: return launch_cfg<T, 1, 2, 2, 2, XF32, I>(p, s);
     case IR_LIN_TILE_128x256: return launch_cfg<T, 2, 2, 2, 4, XF32, I>(p, s);
+    case IR_LIN_TILE_128x128_K2: return launch_cfg<T, 2, 2, 2, 2, XF32, I, 2>(p, s);   // contraction split over two wave groups
     case IR_LIN_TILE_256x256: return launch_pp<T, XF32>(p, s);   // wave groups one phase apart: 1-4 % over the same tile with all
                                                                   // waves in one phase (launch_cfg<T, 4, 2, 2, 4, XF32, I>), and a ragged last column tile
     default: return hipErrorInvalidValue;
@@ -622,16 +661,21 @@ hipError_t launch_x(const LinearKParams& p, int cfg, hipStream_t s) {
 // tile (64 x 128 per wave: 0.75 LDS fragment reads per MFMA, half the L2 traffic per flop of 128x128; ragged last column
 // tile allowed) wins as soon as its grid covers ~160 of the 256 CUs; below that 128x128 at two workgroups per CU, and
 // 64-row tiles when even that grid leaves CUs idle
-int ir_linear_tiled_pick(int64_t M, int N) {
+// Round 5: where the 128x128 grid leaves a third of the CUs idle and the contraction is long (M = 2048 rows x N = 1280, K = 1280:
+// 160 tiles), the split-K form of that tile (two wave groups, half the K loop each) leads by 8-12 %
+// (profiles/r5_gemm_probe_final.txt: 14.4 -> 13.2 us with 16-bit activations, 22.7 -> 19.9 with fp32 ones); with more tiles than
+// CUs it loses (one 128-KiB workgroup per CU instead of two), so the rule is narrow.
+int ir_linear_tiled_pick(int64_t M, int N, int K) {
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (int64_t)((N + bn - 1) / bn); };
   if (tiles(256, 256) >= 160) return IR_LIN_TILE_256x256;
+  if (N % 128 == 0 && tiles(128, 128) >= 128 && tiles(128, 128) <= 192 && K >= 1024 && ((K >> 6) & 1) == 0) return IR_LIN_TILE_128x128_K2;
   if (N % 128 == 0) return tiles(128, 128) >= 128 ? IR_LIN_TILE_128x128 : IR_LIN_TILE_64x128;
   return tiles(256, 64) >= 512 ? IR_LIN_TILE_256x64 : IR_LIN_TILE_128x64;
 }
 
 bool ir_linear_tiled_cfg_ok(int cfg, int N) {
   switch (cfg) {
-    case IR_LIN_TILE_256x128: case IR_LIN_TILE_128x128: case IR_LIN_TILE_64x128: return N % 128 == 0;
+    case IR_LIN_TILE_256x128: case IR_LIN_TILE_128x128: case IR_LIN_TILE_64x128: case IR_LIN_TILE_128x128_K2: return N % 128 == 0;
     case IR_LIN_TILE_128x64: case IR_LIN_TILE_256x64: return N % 64 == 0;
     case IR_LIN_TILE_128x256: return N % 256 == 0;
     case IR_LIN_TILE_256x256: return N % 64 == 0;         // ragged last column tile

@@ -580,15 +580,15 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     // zero-filled references in closed form (ABI v8): (N - nref) * Lr keys that all score exactly 0 and carry a zero value
     // row (with the fold: the AdaIN shift b).  The reference moves up to 0 if it was below; everything accumulated is
     // rescaled once; the row sum takes cnt * 2^(-m) and the folded total that weight times the suffix's summed shifts.
-    const float cnt = (float)(p.N - nref) * (float)p.Lr;
+    const float nz = (float)(p.N - nref);
     if (!PRESC && m_run == -INFINITY) m_run = 0.f;             // no tile walked at all
     const float e = PRESC ? -m_run : -m_run * c2;
     const float up = max3(e, 0.f, 0.f);
     const float alpha = fast_exp2(-up);
     m_run += PRESC ? up : up / c2;
-    const float pz = fast_exp2(e - up) * cnt;
+    const float pz = fast_exp2(e - up) * (float)p.Lr;          // weight of ONE zero segment (Lr keys); bs below sums the segments' shifts
     if (FOLD) {
-      l_tot = l_tot * alpha + pz;
+      l_tot = l_tot * alpha + pz * nz;
       m_ot = m_run;
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
       la *= alpha;
       lb *= alpha;
-      if (hi == 0) la[0] += pz;                                // the two lanes of a row add their partial sums below
+      if (hi == 0) la[0] += pz * nz;                           // the two lanes of a row add their partial sums below
     }
   }
   float l_fin;

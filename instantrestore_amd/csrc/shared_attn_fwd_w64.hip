@@ -554,8 +554,8 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   // closed the ratio frame with a_next = 1).  Without the fold the value rows are 0 and only the row sum moves.
   if (nref < p.N && piece == npiece - 1) {
     const KArgs c = cold();
-    const float cnt = (float)(c->N - nref) * (float)c->Lr;
-    auto zero_suffix = [&](RowBlock& R) -> float {
+    const float nz = (float)(c->N - nref), lr = (float)c->Lr;
+    auto zero_suffix = [&](RowBlock& R) -> float {   // returns the weight of ONE zero segment (Lr keys)
       if (!QS && R.m_run == -INFINITY) R.m_run = 0.f;          // no tile walked at all: the reference starts at the zero score
       const float e = QS ? -R.m_run : -R.m_run * c2;           // exponent of a zero score relative to the reference
       const float up = max3(e, 0.f, 0.f);
@@ -566,9 +566,9 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       R.lb *= alpha;
       if (FOLD) R.l_done *= alpha;
       R.m_run += QS ? up : up / c2;
-      const float pz = fast_exp2(e - up) * cnt;
-      if (FOLD) R.l_done += pz;
-      else if (hi == 0) R.la[0] += pz;                         // the two lanes of a row add their partial sums in finish()
+      const float pz = fast_exp2(e - up) * lr;
+      if (FOLD) R.l_done += pz * nz;
+      else if (hi == 0) R.la[0] += pz * nz;                    // the two lanes of a row add their partial sums in finish()
       return pz;
     };
     const float pzA = zero_suffix(A), pzB = zero_suffix(Bk);

@@ -427,8 +427,8 @@ def tensor2im_u8(x: torch.Tensor) -> torch.Tensor:
 
 
 LIN_AUTO, LIN_X_STATIONARY, LIN_TILED_FIRST = 0, 1, 2   # IR_LIN_* of include/instantrestore_hip.h
-LIN_KERNELS = {"auto": 0, "x_stationary": 1, "256x128": 2, "128x128": 3, "128x64": 4, "256x64": 5, "64x128": 6, "128x256": 7, "256x256": 8}
-LIN_KERNELS_DEV = {"x_stationary_pp": 9, "x_stationary_rot": 10}   # development builds only (tools/experiments)
+LIN_KERNELS = {"auto": 0, "x_stationary": 1, "256x128": 2, "128x128": 3, "128x64": 4, "256x64": 5, "64x128": 6, "128x256": 7, "256x256": 8,
+               "128x128k2": 9}   # 9 (round 5): 128 x 128 tile, contraction split over two wave groups (K / 64 even)
 
 
 def linear_supported(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> bool:

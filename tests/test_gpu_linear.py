@@ -59,7 +59,7 @@ def test_linear_exact_column_order_and_strided_input():
     assert torch.equal(y6.float(), (x6.float() @ w6.float().T + b.float()).to(torch.bfloat16).float())
 
 
-TILED = ["256x128", "128x128", "128x64", "256x64", "64x128", "128x256", "256x256"]
+TILED = ["256x128", "128x128", "128x64", "256x64", "64x128", "128x256", "256x256", "128x128k2"]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
@@ -74,8 +74,10 @@ def test_tiled_linear_matches_float64(dtype, kernel, M, N, K, bias):
     same 16-bit inputs; with fp32 activations the result must be the SAME BITS as with the pre-cast ones (the fused cast is
     `.to(dtype)`)"""
     from instantrestore_amd import ops
-    if N % (64 if kernel.startswith("256x256") else int(kernel.split("x")[1])) != 0:   # 256x256: ragged last column tile
+    if N % (64 if kernel.startswith("256x256") else int(kernel.split("x")[1].split("k")[0])) != 0:   # 256x256: ragged last column tile
         pytest.skip("tile width does not divide N")
+    if kernel.endswith("k2") and (K // 64) % 2:
+        pytest.skip("the split-K tile takes an even number of 64-wide K steps")
     kid = ops.LIN_KERNELS[kernel]
     g = torch.Generator().manual_seed(M * 7 + N + K)
     x32 = torch.randn(M, K, generator=g)
@@ -117,6 +119,25 @@ def test_tiled_linear_exact_layout(kernel):
     ref = (x.float() @ wbig[256:512].float().T + b.float())
     assert y.shape == (3, 333, 256)
     assert torch.equal(y.float(), ref.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(2048, 1280, 1280, True), (2048, 3840, 1280, False), (333, 256, 640, True)])
+def test_split_k_tile_is_bit_stable(M, N, K, bias):
+    """the split-K tile (round 5) adds its two K halves in ONE fixed order through LDS - no atomics, nothing through memory:
+    50 launches, fp32 and 16-bit activations, the same bits every time (and the fused cast is still `.to(dtype)`)"""
+    from instantrestore_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x32 = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    b = torch.randn(N, generator=g).to(torch.bfloat16).cuda() if bias else None
+    kid = ops.LIN_KERNELS["128x128k2"]
+    first = ops.linear(x32, w, b, kernel=kid)
+    assert torch.equal(first, ops.linear(x32.to(torch.bfloat16), w, b, kernel=kid))
+    for _ in range(50):
+        assert torch.equal(ops.linear(x32, w, b, kernel=kid), first)
+    # against the single-pass tile: same product, another fp32 summation order - within one 16-bit rounding of each other
+    ref = ops.linear(x32, w, b, kernel=ops.LIN_KERNELS["128x128"])
+    assert float((first.float() - ref.float()).abs().max()) <= 2.0 ** -7 * max(1.0, float(ref.float().abs().max()))
 
 
 def test_linear_auto_choice_covers_every_projection_of_the_topology():

@@ -7,7 +7,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from instantrestore_amd import attn_processors as ap, ops
-ops.LIN_KERNELS = {**ops.LIN_KERNELS, **ops.LIN_KERNELS_DEV}   # ids 9 / 10 exist in development builds (IR_LIB_PATH)
 
 what = sys.argv[1] if len(sys.argv) > 1 else "ref_stats"
 dev = torch.device("cuda", 0)

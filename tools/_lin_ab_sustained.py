@@ -5,7 +5,6 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from instantrestore_amd import ops
-ops.LIN_KERNELS = {**ops.LIN_KERNELS, **ops.LIN_KERNELS_DEV}   # ids 9 / 10 exist in development builds (IR_LIB_PATH)
 M, N, K, bias, f32 = (int(a) for a in sys.argv[1:6])
 kernels = sys.argv[6:]
 secs, rounds = float(os.environ.get("SECS", "1.0")), int(os.environ.get("ROUNDS", "3"))

@@ -4,7 +4,6 @@ import os, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from instantrestore_amd import ops
-ops.LIN_KERNELS = {**ops.LIN_KERNELS, **ops.LIN_KERNELS_DEV}   # ids 9 / 10 exist in development builds (IR_LIB_PATH)
 M, N, K = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 kid = ops.LIN_KERNELS[sys.argv[4]]
 f32 = len(sys.argv) > 5 and sys.argv[5] == "fp32"

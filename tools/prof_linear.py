@@ -5,7 +5,6 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from instantrestore_amd import ops
-ops.LIN_KERNELS = {**ops.LIN_KERNELS, **ops.LIN_KERNELS_DEV}   # ids 9 / 10 exist in development builds (IR_LIB_PATH)
 M, N, K = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (131072, 960, 320)
 kid = ops.LIN_KERNELS[sys.argv[4]] if len(sys.argv) > 4 else 0
 f32 = len(sys.argv) > 5 and sys.argv[5] == "fp32"

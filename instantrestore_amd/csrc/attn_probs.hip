@@ -193,7 +193,15 @@ __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKPa
       }
       ir_wave_lds_fence();   // every read issued before the first store waits for its data
 #pragma unroll
-      for (int t = 0; t < NST; ++t) __builtin_amdgcn_raw_buffer_store_b128(v[t], prs, obase + (unsigned)t * row_pitch, 0, 0);
+      // nt (non-temporal, aux bit 1 on gfx940+): P is written once and never read here, K is re-read by every wave from L2 - the
+      // streaming hint keeps the 6.7 GB of P from pushing K out of the 4-MiB L2s.  A/B of the cache-policy bits on one box, top
+      // layer (tools/_probs_aux_probe.py): plain 1.69-1.74 ms, nt 1.49-1.53, sc1 / sc0 sc1 (write-through) 1.70-1.74, sc1 nt
+      // 1.53; whole probe on the next box (profiles/r5_probs_probe.txt): 1.23 ms = 5.4 TB/s, L = 1024 0.26 -> 0.18 ms.
+      // -DPROBS_STORE_AUX=<bits> rebuilds the A/B (1 sc0, 2 nt, 16 sc1).
+#ifndef PROBS_STORE_AUX
+#define PROBS_STORE_AUX 2
+#endif
+      for (int t = 0; t < NST; ++t) __builtin_amdgcn_raw_buffer_store_b128(v[t], prs, obase + (unsigned)t * row_pitch, 0, PROBS_STORE_AUX);
       ooff += (unsigned)PITCH;
     }
   }

@@ -118,8 +118,27 @@ static __device__ __forceinline__ void buffer_load_lds16_async(i32x4 rsrc, unsig
 // lane; what the hardware range-checks against num_records: lanes past it are dropped) + soffset (wave-uniform, SGPR).
 // A kernel that sends every store of a wave through ONE per-lane offset keeps one register where per-store 64-bit
 // addresses were sixteen (linear_skinny.hip).  Counts in vmcnt like any store; hipcc's own waits only get stricter.
+// Cache policy of the projection GEMMs' OUTPUT stores: non-temporal since round 5 (-DIR_LIN_STORE_NT=0 rebuilds the plain form).
+// Y is written once by the GEMM and is larger than the L2s for every big shape; without the hint its lines push the operand
+// panels out.  Same-box A/B over the twelve step shapes (tools/_lin_nt_ab.py, three alternations): 1.79 -> 1.71 ms per step of
+// GEMM time in isolation, 131072 x 960 x 320 with fp32 activations 121 -> 100 us; the two-stream step itself is within its noise
+// (7.06 vs 7.02 ms): under the power cap and beside the other stream's attention the GEMMs are not what the step waits for.
+#ifndef IR_LIN_STORE_NT
+#define IR_LIN_STORE_NT 1
+#endif
 static __device__ __forceinline__ void buffer_store16_async(i32x4 rsrc, u32x4 v, unsigned voffset, unsigned soffset) {
+#if IR_LIN_STORE_NT
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt" : : "v"(v), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+#else
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(v), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+#endif
+}
+static __device__ __forceinline__ void ir_store_y(u32x4* p, u32x4 v) {
+#if IR_LIN_STORE_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
 }
 
 static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }

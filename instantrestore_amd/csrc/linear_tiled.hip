@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(WM * WN * KW * 64, KW == 1 ? 2 : 1) linear_til
       const int r = 8 * j + (lane >> 3);
       const u32x4 v = *(const u32x4_alias*)(tb + r * kTiledPitch + (lane & 7) * 16);
       const int row = row_base + r;
-      if (row < p.M) *(u32x4*)((T*)p.y + (int64_t)row * p.y_ld + ncol0 + (lane & 7) * 8) = v;
+      if (row < p.M) ir_store_y((u32x4*)((T*)p.y + (int64_t)row * p.y_ld + ncol0 + (lane & 7) * 8), v);
       if (st_on) {
         if (j == 0) ir_stats_first<T>(sacc, v);
         else ir_stats_add<T>(sacc, v);
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(512, 2) linear_tiled_pp_kernel(const LinearKPa
             const int r = 8 * j + (lane >> 3);
             const u32x4 v = *(const u32x4_alias*)(tb + r * kTiledPitch + (lane & 7) * 16);
             const int row = em0 + wm * (MI * 32) + mi * 32 + half * 16 + r;
-            if (row < p.M) *(u32x4*)((T*)p.y + (int64_t)row * p.y_ld + ncol0 + (lane & 7) * 8) = v;
+            if (row < p.M) ir_store_y((u32x4*)((T*)p.y + (int64_t)row * p.y_ld + ncol0 + (lane & 7) * 8), v);
             if (st_on) {
               if (mi == 0 && half == 0 && j == 0) ir_stats_first<T>(sacc, v);
               else ir_stats_add<T>(sacc, v);

@@ -1194,6 +1194,9 @@ def main():
                 "identities_per_gpu": B, "global_batch": total_ids, "refs": N, "px": px,
                 "use_adain": use_adain, "train_input": train_input, "ref_early_exit": bool(args.ref_early_exit), "two_streams": bool(args.two_streams), "launch": launch_mode, "graph_capture_error": graph_error, "parallelism": "dp%d (independent identities)" % world,
                 "activations": "fp32 under torch.autocast (test.py:61-83)" if act_fp32 else "pre-cast to the 16-bit dtype",
+                "layer_dependence": "none: the nine layer pairs of the synthetic step are independent token sets (the UNet body that would chain them "
+                                    "is out of scope), so a replayed graph / two streams may overlap ANY of them; in the real UNet layer i+1 waits for "
+                                    "layer i of its own UNet and only the two UNets overlap (the one-stream figure under extras is the no-overlap bound)",
                 "rccl_ranks": (dist.get_world_size() if use_dist else 1),
                 "rccl_communicator": ("real (%d ranks)" % dist.get_world_size()) if use_dist else "none: %s" % ((single_rank_comm or {}).get("error") or "IR_BENCH_FORCE_DIST=0"),
                 "scatter_gather_ms": None if not extras else extras.get("scatter_gather", {}).get("scatter_gather_ms"),

@@ -233,6 +233,14 @@ def test_golden_shared_processor(ops, golden, m):
     # peaky cases) dominates and is shared with the reference's own 16-bit run: never be worse
     # than that run where it exceeds the kernel bound
     assert err <= max(bound, ref_err), f"{m['id']}: ours {err:.3e} > bound {bound:.3e} and reference lowp {ref_err:.3e}"
+    if m.get("valid"):
+        # the fixture's references n >= valid[b] were zero-filled the way pix2pix_turbo.py:269-273 does before the REFERENCE ran:
+        # told the counts (round 5, ABI v8 valid_refs) the kernel closes those segments analytically - same reference output
+        vd = torch.tensor(m["valid"], dtype=torch.int32, device="cuda")
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+            out_v = attn(hidden, encoder_hidden_states=enc, ref_valid=vd, **kwargs)
+        err_v = np.abs(out_v.float().cpu().numpy() - ref).max()
+        assert err_v <= max(bound, ref_err), f"{m['id']} with valid_refs: {err_v:.3e} > bound {bound:.3e} and reference lowp {ref_err:.3e}"
     if m["save_probs"]:
         p_ref = golden.arr(m, "probs")
         p = proc.attention_probs

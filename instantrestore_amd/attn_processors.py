@@ -391,6 +391,12 @@ class SharedAttnProcessor(nn.Module):
         self.save_self_attentions = save_self_attentions
         self.use_adain = use_adain
         self.train_input = train_input
+        # opt-in (round 5; a plain attribute like ``AttnProcessor.record_events``, the constructor stays the reference's): when set,
+        # every call also leaves ``attention_mass`` - fp32 (B, H, L, [self?] + N), the attention mass per K/V segment - which is what
+        # gradio_demo.py:119-127 reduces ``attention_probs`` to (``probs[..., attn_size*idx : attn_size*(idx+1)].sum(-1)``), without
+        # the (B, H, L, Lkv) tensor (``ir_attn_segment_mass``).  Independent of ``save_self_attentions``, whose meaning is unchanged.
+        self.save_attention_mass = False
+        self.attention_mass = None
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                 ref_keys=None, ref_values=None, ref_events=None, ref_stats=None, ref_valid=None):
@@ -448,11 +454,17 @@ class SharedAttnProcessor(nn.Module):
         _same_16bit(query, key, value, ref_k, ref_v)
 
         want_probs = bool(self.save_self_attentions)
+        want_mass = bool(getattr(self, "save_attention_mass", False))
         kw = {"q_prescaled": True} if presc else {}
         if shared and ref_valid is not None:
             kw["valid_refs"] = ref_valid
         res = _ops.shared_attention(query, key, value, ref_k, ref_v, heads=attn.heads, scale=attn.scale,
-                                    include_self=include_self, adain=affine, return_lse=want_probs, **kw)
+                                    include_self=include_self, adain=affine, return_lse=want_probs or want_mass, **kw)
+        if want_mass:
+            self.attention_mass = _ops.attn_segment_mass(query, key, ref_k, res[1], heads=attn.heads,
+                                                         scale=0.6931471805599453 if presc else attn.scale, include_self=include_self)
+            if not want_probs:
+                res = res[0]
         if want_probs:
             tokens, lse = res
             # (B, H, L, Lkv), columns [self?] ++ ref0 ++ ... ++ refN-1, in the compute dtype.  A pre-scaled query

@@ -154,3 +154,32 @@ def test_segment_mass(ops, case, dtype):
     m = mass.cpu().numpy()
     assert np.abs(m - m_ref).max() <= 2e-3, np.abs(m - m_ref).max()
     np.testing.assert_allclose(m.sum(-1), 1.0, atol=2e-3)
+
+
+def test_processor_attention_mass_is_the_block_sum_of_attention_probs(ops):
+    """opt-in ``SharedAttnProcessor.save_attention_mass``: the per-reference mass a gradio_demo.py:119-127-style consumer needs,
+    equal to the block sums of the ``attention_probs`` the same call dumps (fp32 sums of the 16-bit probabilities: 4 x TOL)"""
+    from face_replace.models.attn_processors import SharedAttnProcessor
+    from instantrestore_amd.attention import Attention
+    torch.manual_seed(4)
+    B, H, L, N = 2, 2, 256, 4
+    C = H * 64
+    for train_input in (True, False):
+        proc = SharedAttnProcessor(self_attn_idx=0, save_self_attentions=True, use_adain=True, train_input=train_input)
+        proc.save_attention_mass = True
+        attn = Attention(query_dim=C, heads=H, dim_head=64, processor=proc).cuda()
+        x = torch.randn(B, L, C, device="cuda")
+        rk = torch.randn(B, N, L, C, device="cuda", dtype=torch.bfloat16)
+        rv = torch.randn(B, N, L, C, device="cuda", dtype=torch.bfloat16)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            attn(x, ref_keys=[rk], ref_values=[rv])
+        S = N + int(train_input)
+        assert proc.attention_mass.shape == (B, H, L, S) and proc.attention_mass.dtype == torch.float32
+        blocks = proc.attention_probs.float().reshape(B, H, L, S, L).sum(-1)
+        assert float((proc.attention_mass - blocks).abs().max()) <= 4 * 8e-3
+        assert float((proc.attention_mass.sum(-1) - 1).abs().max()) <= 2e-3
+        proc.save_self_attentions = False          # the mass alone: no (B, H, L, Lkv) tensor is formed
+        proc.attention_probs = None
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            attn(x, ref_keys=[rk], ref_values=[rv])
+        assert proc.attention_probs is None and float((proc.attention_mass.sum(-1) - 1).abs().max()) <= 2e-3

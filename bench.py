@@ -971,9 +971,15 @@ def main():
         # N = 1 (round 5): the barrier, the MAX-over-ranks reduction and the scatter / gather leg run through
         # a real one-rank RCCL communicator, so that the first 8-GPU run is not also the first RCCL run.  Never at the price of
         # the headline: any failure falls back to the plain single-process path and is reported in extras.scatter_gather.
-        single_rank_comm = init_single_rank_nccl(dev)
+        #   ... and never at the price of the run either: the bring-up happens under a watchdog (a communicator that never
+        #   comes up must not keep the headline from being measured); a stuck helper thread is left behind and the process leaves
+        #   through os._exit once its line is printed
+        single_rank_comm, init_hung = _guarded(lambda: init_single_rank_nccl(dev), dev, float(os.environ.get("IR_BENCH_RCCL_INIT_TIMEOUT", "90")))
+        if init_hung or not isinstance(single_rank_comm, dict) or "ok" not in single_rank_comm:
+            single_rank_comm = {"ok": False, "error": (single_rank_comm or {}).get("error", "one-rank RCCL bring-up failed"), "init_hung": bool(init_hung)}
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     use_dist = world > 1 or (single_rank_comm is not None and single_rank_comm.get("ok"))
+    leave_hard = bool(single_rank_comm and single_rank_comm.get("init_hung"))
 
     train_input = bool(args.train_input)
     if args.variant:
@@ -1215,6 +1221,9 @@ def main():
             os.dup2(2, 1)
         except OSError:
             pass
+    if leave_hard:      # a helper thread is still inside the RCCL bring-up: no interpreter teardown behind it
+        sys.stdout.flush()
+        os._exit(0)
     if world == 1 and use_dist:
         if hung:
             os._exit(0)

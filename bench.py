@@ -333,7 +333,7 @@ def kernel_class_breakdown(layers, B, N, steps):
 
 
 def _pmc_profile_name():
-    for name in ("r4_pmc_shared_attn.txt", "r3_pmc_shared_attn.txt", "r2_pmc_shared_attn.txt", "r1_pmc_shared_attn.txt"):
+    for name in ("r5_pmc_shared_attn.txt", "r4_pmc_shared_attn.txt", "r3_pmc_shared_attn.txt", "r2_pmc_shared_attn.txt", "r1_pmc_shared_attn.txt"):
         if os.path.exists(os.path.join(REPO, "profiles", name)):
             return "profiles/" + name
     return "no committed PMC profile"

@@ -82,8 +82,7 @@ def harvest_reference_kv(original_unet, n_refs: int, valid_indices: Sequence[int
                 v.record_stream(cur)
         for k, v in zip(keys, values):
             _ops.zero_invalid_refs(k, v, valid, heads=k.shape[-1] // _ops.HEAD_DIM)
-        if keys[0].is_cuda:
-            valid_out = valid.to(device=keys[0].device, dtype=torch.int32).contiguous()
+        valid_out = valid.to(device=keys[0].device, dtype=torch.int32).contiguous()
         if with_stats and keys[0].is_cuda:
             # the zero fill invalidates the cached statistics of the zeroed references: an all-zero V has mean 0, std 0
             keep = (torch.arange(n_refs)[None, :] < valid.reshape(-1, 1)).to(device=keys[0].device, dtype=torch.float32)[:, :, None, None]

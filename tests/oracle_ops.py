@@ -20,9 +20,15 @@ def _np(t):
 
 
 def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads, scale, include_self=True,
-                     adain=None, return_lse=False):
+                     adain=None, return_lse=False, valid_refs=None):
+    """``valid_refs``: the caller's promise that references n >= valid_refs[b] are all-zero; the oracle walks them like any
+    other (that IS the semantics: zeroed, not masked) and the stand-in only checks the promise"""
     CALLS.append(("shared_attention", dict(include_self=include_self, adain=adain is not None,
-                                           n_refs=0 if ref_k is None else ref_k.shape[1])))
+                                           n_refs=0 if ref_k is None else ref_k.shape[1],
+                                           valid_refs=None if valid_refs is None else [int(x) for x in valid_refs.tolist()])))
+    if valid_refs is not None:
+        for b, nv in enumerate(valid_refs.tolist()):
+            assert float(ref_k[b, int(nv):].abs().sum()) == 0.0 and float(ref_v[b, int(nv):].abs().sum()) == 0.0, "valid_refs promise broken"
     qn, kn, vn, rkn, rvn = map(_np, (q, k_self, v_self, ref_k, ref_v))
     if adain is not None:  # apply the affine the stats kernel would have produced
         a, b = (_np(t).reshape(rvn.shape[0], rvn.shape[1], 1, -1) for t in adain)
@@ -44,6 +50,17 @@ def attn_probs(q, k_self, ref_k, lse, *, heads, scale, include_self=True):
     qn, kn, rkn = map(_np, (q, k_self, ref_k))
     _, p = O.shared_attention_np(qn, kn, kn, rkn, rkn, heads, scale, False, include_self, return_probs=True)
     return torch.from_numpy(p).to(q.dtype)
+
+
+def attn_segment_mass(q, k_self, ref_k, lse, *, heads, scale, include_self=True):
+    CALLS.append(("attn_segment_mass", {}))
+    qn, kn, rkn = map(_np, (q, k_self, ref_k))
+    _, p = O.shared_attention_np(qn, kn, kn, rkn, rkn, heads, scale, False, include_self, return_probs=True)
+    edges = [0] + ([kn.shape[1]] if include_self else [])
+    for n in range(0 if rkn is None else rkn.shape[1]):
+        edges.append(edges[-1] + rkn.shape[2])
+    mass = np.stack([p[..., a:b].sum(-1) for a, b in zip(edges[:-1], edges[1:])], axis=-1)
+    return torch.from_numpy(mass).float()
 
 
 def adain_stats(v_self, ref_v, *, heads, eps=ADAIN_EPS):

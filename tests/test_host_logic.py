@@ -136,6 +136,43 @@ def test_two_unet_call_pattern_end_to_end(shim):
     np.testing.assert_allclose(got.numpy(), ref, atol=2e-5, rtol=1e-4)
 
 
+def test_valid_counts_travel_from_the_harvest_to_the_kernel_call(shim):
+    """round 5 (ABI v8): ``harvest_reference_kv(with_valid=True)`` hands out the int32 valid counts when it zero-filled something
+    (None otherwise); as ``cross_attention_kwargs['ref_valid']`` they reach every SHARED layer's kernel call and no other; the
+    opt-in ``save_attention_mass`` leaves the block sums of the probabilities"""
+    from face_replace.models.attn_processors import (SharedAttnProcessor, register_attention_processor,
+                                                     register_attention_processor_kv_unet)
+    from instantrestore_amd.kv_harvest import harvest_reference_kv
+    from instantrestore_amd.unet_host import AttnTopologyUNet
+    mk = lambda seed: AttnTopologyUNet(block_out_channels=(64, 128, 128, 128), attention_head_dim=(1, 2, 2, 2),
+                                       cross_attention_dim=32, seed=seed)
+    kv_unet, unet = mk(3), mk(4)
+    kv_unet.set_attn_processor({n: SharedAttnProcessor(self_attn_idx=None) for n in kv_unet.attn_processors})
+    register_attention_processor_kv_unet(kv_unet)
+    register_attention_processor(unet, SimpleNamespace(use_adain=True, train_input=True, condition_on_face_embeds=False))
+    B, N, S = 2, 3, 8
+    text = torch.randn(1, 5, 32)
+    with torch.no_grad():
+        kv_unet(torch.randn(B * N, 4, S, S), None, encoder_hidden_states=text.repeat(B * N, 1, 1))
+        keys, vals, valid = harvest_reference_kv(kv_unet, N, [3, 3], reset=False, with_valid=True)
+        assert valid is None                                   # nothing zero-filled: nothing to promise
+        keys, vals, valid = harvest_reference_kv(kv_unet, N, [2, 1], with_valid=True)
+        assert valid.dtype == torch.int32 and valid.tolist() == [2, 1]
+        shared = [p for p in unet.attn_processors.values() if type(p) == SharedAttnProcessor and p.self_attn_idx is not None]
+        shared[0].save_attention_mass = True
+        del shim.CALLS[:]
+        y = unet(torch.randn(B, 4, S, S), None, encoder_hidden_states=text.repeat(B, 1, 1),
+                 cross_attention_kwargs={"ref_keys": keys, "ref_values": vals, "ref_valid": valid}).sample
+    assert torch.isfinite(y).all()
+    calls = [c[1] for c in shim.CALLS if c[0] == "shared_attention"]
+    assert sum(1 for c in calls if c["valid_refs"] == [2, 1]) == 9            # the nine shared layers, told the counts
+    assert all(c["valid_refs"] is None for c in calls if c["n_refs"] == 0)    # plain / cross attention: never
+    m = shared[0].attention_mass
+    assert m.shape[0] == B and m.shape[-1] == N + 1 and float((m.sum(-1) - 1).abs().max()) < 1e-5
+    # a zero-filled reference keeps its exp(0) weight: its mass is NOT zero (zeroed, not masked; pix2pix_turbo.py:269-273)
+    assert float(m[1, ..., 2:].min()) > 0
+
+
 SHARED = [m for m in GOLDEN_MANIFEST if m["kind"] == "shared"]
 
 

@@ -119,6 +119,25 @@ def main(argv=None):
         z2 = unet(vae.encode(x), None, encoder_hidden_states=caption.expand(B, -1, -1),
                   cross_attention_kwargs={"ref_keys": ck, "ref_values": cv, "ref_stats": cs}).sample
         assert torch.equal(ops.tensor2im_u8(vae.decode(z2)), out_u8), "cached K/V + statistics must reproduce the frame"
+        # A checkpoint trained with fewer references than the caller hands in (inference/test.py:81 passes ITS
+        # max_conditioning_images as valid count; pix2pix_turbo.py:269-273 zero-fills the rest): told the counts
+        # (cross_attention_kwargs['ref_valid'], what harvest_reference_kv(..., with_valid=True) returns) the kernels close the
+        # zeroed references analytically instead of walking them - same pixels.  And a consumer that only ranks the references
+        # (gradio_demo.py:119-127) asks the top shared layer for its per-reference attention mass instead of attention_probs.
+        if N > 1:
+            valid = torch.full((B,), N - 1, dtype=torch.int32, device=dev)
+            zk, zv = [k.clone() for k in ck], [v.clone() for v in cv]
+            for k, v in zip(zk, zv):
+                ops.zero_invalid_refs(k, v, valid, heads=k.shape[-1] // 64)
+            top = [p for p in unet.attn_processors.values() if getattr(p, "self_attn_idx", None) == 8][0]
+            top.save_attention_mass = True
+            kw = {"ref_keys": zk, "ref_values": zv}          # (no cached statistics here: the zero fill changed them)
+            z3 = unet(vae.encode(x), None, encoder_hidden_states=caption.expand(B, -1, -1), cross_attention_kwargs=dict(kw, ref_valid=valid)).sample
+            mass = top.attention_mass                          # (B, H, L, 1 + N) fp32, rows sum to 1
+            z4 = unet(vae.encode(x), None, encoder_hidden_states=caption.expand(B, -1, -1), cross_attention_kwargs=kw).sample
+            top.save_attention_mass = False
+            assert float((z3.float() - z4.float()).abs().max()) <= 2e-2 * max(1.0, float(z4.float().abs().max()))
+            assert mass.shape[-1] == N + int(top.train_input) and float((mass.sum(-1) - 1).abs().max()) < 2e-3
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert out_u8.shape == (B, S, S, 3) and out_u8.dtype == torch.uint8

@@ -183,3 +183,29 @@ def test_processor_attention_mass_is_the_block_sum_of_attention_probs(ops):
         with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
             attn(x, ref_keys=[rk], ref_values=[rv])
         assert proc.attention_probs is None and float((proc.attention_mass.sum(-1) - 1).abs().max()) <= 2e-3
+
+
+def test_cfg5_top_layer_shape_one_head(ops):
+    """the 1024 px layer class (L = 16 384 query rows, Lkv = 81 920 keys): one (b, h) of the probability matrix is 2.7 GB - the
+    reference itself cannot form the cfg-5 tensor (215 GB at B = 16).  Rows sum to 1, sampled rows equal the oracle's, and the
+    line kernel equals the 2-byte-store kernel on a row band (bit for bit)."""
+    dtype = torch.float16
+    B, H, L, N = 1, 1, 16384, 4
+    g = torch.Generator(device="cuda").manual_seed(2)
+    q = (torch.randn(B, L, 64, device="cuda", generator=g) * 1.2).to(dtype)
+    k = torch.randn(B, L, 64, device="cuda", generator=g).to(dtype)
+    v = torch.randn(B, L, 64, device="cuda", generator=g).to(dtype)
+    rk = torch.randn(B, N, L, 64, device="cuda", generator=g).to(dtype)
+    rv = torch.randn(B, N, L, 64, device="cuda", generator=g).to(dtype)
+    _, lse = ops.shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, include_self=True, return_lse=True)
+    probs = ops.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=True)
+    assert probs.shape == (B, H, L, 5 * L)
+    sums = probs.float().sum(-1)
+    assert float((sums - 1).abs().max()) <= 4 * TOL[dtype]
+    rows = sorted(set(np.random.default_rng(1).integers(0, L, 40).tolist() + [0, 63, 64, L - 1]))
+    _, p_ref = O.shared_attention_np(_np64(q)[:, rows], _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.125, False, True, return_probs=True)
+    assert np.abs(probs[:, :, rows].float().cpu().numpy() - p_ref).max() <= TOL[dtype]
+    band = slice(4096, 4096 + 512)
+    lse_b = lse[:, :, band].contiguous()
+    a = ops.attn_probs(q[:, band].contiguous(), k, rk, lse_b, heads=H, scale=0.125, include_self=True, kernel="generic")
+    assert torch.equal(a, probs[:, :, band])

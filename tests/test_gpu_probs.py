@@ -209,3 +209,42 @@ def test_cfg5_top_layer_shape_one_head(ops):
     lse_b = lse[:, :, band].contiguous()
     a = ops.attn_probs(q[:, band].contiguous(), k, rk, lse_b, heads=H, scale=0.125, include_self=True, kernel="generic")
     assert torch.equal(a, probs[:, :, band])
+
+
+def test_randomised_shapes_line_kernels_equal_the_generic_kernel(ops):
+    """seeded sweep over ragged shapes (IR_SWEEP_CASES widens it): every line kernel must reproduce the 2-byte-store kernel bit
+    for bit wherever it applies, rows sum to 1, and lengths that are not multiples of 8 must still work through `auto`"""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("IR_SWEEP_SEED", "77")))
+    gen = torch.Generator().manual_seed(77)
+    for case in range(int(os.environ.get("IR_SWEEP_CASES", "24"))):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        unit = 8 if case % 4 else 1                       # every fourth case: lengths that are NOT multiples of 8
+        Lq = int(rng.integers(1, 400))
+        Ls = int(rng.integers(1, 60)) * unit
+        N = int(rng.integers(0, 6))
+        Lr = int(rng.integers(1, 50)) * unit if N else 0
+        inc = bool(rng.integers(0, 2)) or N == 0
+        dtype = [torch.float16, torch.bfloat16][case % 2]
+        C = H * 64
+        q = _rand((B, Lq, C), dtype, gen, 1.4).cuda()
+        k, v = _rand((B, Ls, C), dtype, gen, 1.4).cuda(), _rand((B, Ls, C), dtype, gen).cuda()
+        rk = _rand((B, N, Lr, C), dtype, gen, 1.4).cuda() if N else None
+        rv = _rand((B, N, Lr, C), dtype, gen).cuda() if N else None
+        what = f"case {case}: B{B} H{H} Lq{Lq} Ls{Ls} N{N} Lr{Lr} inc{inc} {dtype}"
+        if inc and Ls != Lq:
+            # self K/V of another length than the query axis: cross-attention through the same entry point
+            pass
+        _, lse = ops.shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, include_self=inc, return_lse=True)
+        ref = ops.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=inc, kernel="generic")
+        auto = ops.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=inc)
+        assert torch.equal(auto, ref), what
+        assert float((ref.float().sum(-1) - 1).abs().max()) <= 4 * TOL[dtype], what
+        aligned = (not inc or Ls % 8 == 0) and (N == 0 or Lr % 8 == 0)
+        for kern in LINE_KERNELS:
+            if aligned:
+                assert torch.equal(ops.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=inc, kernel=kern), ref), (what, kern)
+        mass = ops.attn_segment_mass(q, k, rk, lse, heads=H, scale=0.125, include_self=inc)
+        edges = [0] + ([Ls] if inc else []) + [(Ls if inc else 0) + (n + 1) * Lr for n in range(N)]
+        blocks = torch.stack([ref[..., a:b].float().sum(-1) for a, b in zip(edges[:-1], edges[1:])], dim=-1)
+        assert float((mass - blocks).abs().max()) <= 4 * TOL[dtype], what

@@ -140,3 +140,29 @@ def test_processor_takes_the_valid_counts_from_the_harvest(ops):
         a = attn(x, ref_keys=[rk], ref_values=[rv], ref_valid=valid)
         b = attn(x, ref_keys=[rk], ref_values=[rv])
     assert float((a.float() - b.float()).abs().max()) <= 2 * 8e-3 * max(1.0, float(b.float().abs().max()))
+
+
+def test_randomised_valid_counts_equal_the_walk(ops):
+    """seeded sweep (IR_SWEEP_CASES widens it): ragged shapes, random valid counts per batch entry, with and without the self
+    segment and AdaIN: telling the kernel the counts must give what walking the zero-filled references gives (2 x TOL: another
+    fp32 summation order), on every product kernel that implements the closed form and on those that ignore the promise"""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("IR_SWEEP_SEED", "91")))
+    for case in range(int(os.environ.get("IR_SWEEP_CASES", "24"))):
+        B, H = int(rng.integers(1, 5)), int(rng.integers(1, 3))
+        L = int(rng.integers(8, 600))
+        N = int(rng.integers(1, 7))
+        Lr = int(rng.integers(8, 300))
+        inc = bool(rng.integers(0, 2))
+        adain = bool(rng.integers(0, 2))
+        dtype = [torch.float16, torch.bfloat16][case % 2]
+        valid = [int(x) for x in rng.integers(0, N + 1, B)]
+        variant = [0, 0, 10, 13, 7][case % 5]          # default dispatch, 32-row kernels, 64-row kernel, exact-max form (walks)
+        q, k, v, rk, rv = _case(B, H, L, N, Lr, dtype, seed=500 + case)
+        a, lse_a, _, _ = _run(ops, q, k, v, rk, rv, valid, H, inc, adain, variant=variant)
+        b, lse_b, _, _ = _run(ops, q, k, v, rk, rv, valid, H, inc, adain, variant=variant, pass_valid=False)
+        what = f"case {case}: B{B} H{H} L{L} N{N} Lr{Lr} inc{inc} adain{adain} valid{valid} variant{variant} {dtype}"
+        bound = 2 * TOL[dtype] * max(1.0, float(b.float().abs().max()))
+        assert torch.isfinite(a.float()).all(), what
+        assert float((a.float() - b.float()).abs().max()) <= bound, what
+        assert float((lse_a - lse_b).abs().max()) <= 2e-3, what

@@ -287,10 +287,16 @@ __global__ void __launch_bounds__(PW * 64) attn_probs_generic_kernel(const AttnK
   }
 }
 
-static int device_cus() {
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  return cus;
+static int device_cus() {   // per device, looked up once (idempotent: a race between threads only repeats the query)
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[dev] = cus;
+  }
+  return cached[dev];
 }
 
 // Cut of the key axis: the largest chunk (whole segments first) that still leaves >= 16 workgroups per CU; never below 256 keys.

@@ -461,8 +461,8 @@ class SharedAttnProcessor(nn.Module):
         res = _ops.shared_attention(query, key, value, ref_k, ref_v, heads=attn.heads, scale=attn.scale,
                                     include_self=include_self, adain=affine, return_lse=want_probs or want_mass, **kw)
         if want_mass:
-            self.attention_mass = _ops.attn_segment_mass(query, key, ref_k, res[1], heads=attn.heads,
-                                                         scale=0.6931471805599453 if presc else attn.scale, include_self=include_self)
+            self.attention_mass = _ops.attn_segment_mass(query, key, ref_k, res[1], heads=attn.heads, scale=attn.scale,
+                                                         include_self=include_self, q_prescaled=bool(presc))
             if not want_probs:
                 res = res[0]
         if want_probs:

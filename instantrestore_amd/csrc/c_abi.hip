@@ -196,6 +196,7 @@ int ir_attn_probs_ex(const ir_shared_attn_args* args, void* probs, int32_t kerne
   if (probs == nullptr || args->lse == nullptr) return fail(IR_ERR_INVALID_ARG, "probs/lse is NULL");
   if (kernel < IR_PROBS_AUTO || kernel > IR_PROBS_LINES32_K256) return fail(IR_ERR_UNSUPPORTED, "attn_probs kernel %d", kernel);
   p.probs = probs;
+  if (p.q_prescaled) p.scale_log2 = 1.0f;   // IR_FLAG_Q_PRESCALED: the products of q and k ARE the exponents (`scale` is the LSE's unit only)
   if (kernel >= IR_PROBS_LINES64 && !ir_attn_probs_uses_lines(p))
     return fail(IR_ERR_UNSUPPORTED, "the line kernel needs len_self, len_ref (and so Lkv) to be multiples of 8 and probs 16-byte aligned");
   const hipError_t e = ir_launch_attn_probs(p, args->dtype, kernel, (hipStream_t)stream);
@@ -210,6 +211,7 @@ int ir_attn_segment_mass(const ir_shared_attn_args* args, float* mass, void* str
   const int rc = build_attn_params(args, &p, false);
   if (rc != IR_OK) return rc;
   if (mass == nullptr || args->lse == nullptr) return fail(IR_ERR_INVALID_ARG, "mass/lse is NULL");
+  if (p.q_prescaled) p.scale_log2 = 1.0f;
   const hipError_t e = ir_launch_attn_segment_mass(p, args->dtype, mass, (hipStream_t)stream);
   if (e != hipSuccess) return fail(IR_ERR_LAUNCH, "attn_segment_mass launch: %s", hipGetErrorString(e));
   return IR_OK;

@@ -267,32 +267,35 @@ def shared_attention_kernel_name(q, k_self, v_self, ref_k=None, ref_v=None, *, h
 PROBS_KERNELS = {"auto": 0, "generic": 1, "lines64": 2, "lines32": 3, "lines32k128": 4, "lines64k128": 5, "lines32k256": 6}   # IR_PROBS_*
 
 
-def _probs_args(q, k_self, ref_k, lse, heads, scale, include_self):
+def _probs_args(q, k_self, ref_k, lse, heads, scale, include_self, q_prescaled=False):
     q, k_self, _, ref_k, _ = _prep(q, k_self, k_self, ref_k, ref_k, heads, include_self, None)
     B, Lq, _ = q.shape
     lkv = (k_self.shape[1] if include_self else 0) + (ref_k.shape[1] * ref_k.shape[2] if ref_k is not None else 0)
     if lse.dtype != torch.float32 or not lse.is_contiguous() or tuple(lse.shape) != (B, heads, Lq):
         raise ValueError("lse must be contiguous fp32 (B, H, Lq)")
-    args = _fill_args(q, k_self, k_self, ref_k, ref_k, heads, scale, include_self, None, None, lse)
+    args = _fill_args(q, k_self, k_self, ref_k, ref_k, heads, scale, include_self, None, None, lse, True, q_prescaled)
     return args, q, B, Lq, lkv, (q, k_self, ref_k, lse)
 
 
 @_on_tensor_device
-def attn_probs(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True, kernel: str = "auto") -> torch.Tensor:
+def attn_probs(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True, kernel: str = "auto",
+               q_prescaled: bool = False) -> torch.Tensor:
     """Materialise ``attention_probs`` (B, H, Lq, Lkv) from the LSE of the fused forward
     (``ir_attn_probs``; the ``save_self_attentions`` dump path, attn_processors.py:258-261).
-    ``kernel``: ``PROBS_KERNELS`` (benchmarks / A-B tests; "auto" is what the processors use)."""
-    args, q, B, Lq, lkv, _keep = _probs_args(q, k_self, ref_k, lse, heads, scale, include_self)
+    ``kernel``: ``PROBS_KERNELS`` (benchmarks / A-B tests; "auto" is what the processors use).  ``q_prescaled``: ``q`` holds
+    ``Q * scale * log2(e)`` (``IR_FLAG_Q_PRESCALED``; ``scale`` stays the reference's ``attn.scale``, the unit of ``lse``)."""
+    args, q, B, Lq, lkv, _keep = _probs_args(q, k_self, ref_k, lse, heads, scale, include_self, q_prescaled)
     probs = torch.empty((B, heads, Lq, lkv), dtype=q.dtype, device=q.device)
     _lib.check(_lib.lib().ir_attn_probs_ex(C.byref(args), probs.data_ptr(), PROBS_KERNELS[kernel], _stream()), "ir_attn_probs")
     return probs
 
 
 @_on_tensor_device
-def attn_segment_mass(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True) -> torch.Tensor:
+def attn_segment_mass(q, k_self, ref_k, lse, *, heads: int, scale: float, include_self: bool = True,
+                      q_prescaled: bool = False) -> torch.Tensor:
     """Attention mass per K/V segment, fp32 (B, H, Lq, include_self + N), without the probability matrix
     (``ir_attn_segment_mass``): what gradio_demo.py:119-127 reduces ``attention_probs`` to."""
-    args, q, B, Lq, _, _keep = _probs_args(q, k_self, ref_k, lse, heads, scale, include_self)
+    args, q, B, Lq, _, _keep = _probs_args(q, k_self, ref_k, lse, heads, scale, include_self, q_prescaled)
     nseg = (1 if include_self else 0) + (ref_k.shape[1] if ref_k is not None else 0)
     mass = torch.empty((B, heads, Lq, nseg), dtype=torch.float32, device=q.device)
     _lib.check(_lib.lib().ir_attn_segment_mass(C.byref(args), mass.data_ptr(), _stream()), "ir_attn_segment_mass")

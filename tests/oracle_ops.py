@@ -45,14 +45,14 @@ def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads, scale,
     return out, torch.from_numpy(lse).float()
 
 
-def attn_probs(q, k_self, ref_k, lse, *, heads, scale, include_self=True):
+def attn_probs(q, k_self, ref_k, lse, *, heads, scale, include_self=True, q_prescaled=False):
     CALLS.append(("attn_probs", {}))
     qn, kn, rkn = map(_np, (q, k_self, ref_k))
     _, p = O.shared_attention_np(qn, kn, kn, rkn, rkn, heads, scale, False, include_self, return_probs=True)
     return torch.from_numpy(p).to(q.dtype)
 
 
-def attn_segment_mass(q, k_self, ref_k, lse, *, heads, scale, include_self=True):
+def attn_segment_mass(q, k_self, ref_k, lse, *, heads, scale, include_self=True, q_prescaled=False):
     CALLS.append(("attn_segment_mass", {}))
     qn, kn, rkn = map(_np, (q, k_self, ref_k))
     _, p = O.shared_attention_np(qn, kn, kn, rkn, rkn, heads, scale, False, include_self, return_probs=True)

@@ -248,3 +248,29 @@ def test_randomised_shapes_line_kernels_equal_the_generic_kernel(ops):
         edges = [0] + ([Ls] if inc else []) + [(Ls if inc else 0) + (n + 1) * Lr for n in range(N)]
         blocks = torch.stack([ref[..., a:b].float().sum(-1) for a, b in zip(edges[:-1], edges[1:])], dim=-1)
         assert float((mass - blocks).abs().max()) <= 4 * TOL[dtype], what
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 2, 72, 3, 40), (1, 2, 300, 2, 136), (1, 1, 1024, 4, 1024)], ids=["L72", "L300", "L1024"])
+def test_segment_mass_with_prescaled_q(ops, dtype, shape):
+    """IR_FLAG_Q_PRESCALED form of the mass kernel (minus the LSE through the MFMA C operand, no multiply-add per score): the
+    same numbers as the plain form on the same pre-scaled q (scale = ln 2 turns its exponents back into logits), and the
+    float64 block sums of softmax(q' k^T ln 2)"""
+    B, H, L, N, Lr = shape
+    C = H * 64
+    gen = torch.Generator().manual_seed(11)
+    q = _rand((B, L, C), dtype, gen, 1.5)
+    qs = (q.float() * (0.125 * 1.4426950408889634)).to(dtype).cuda()          # what the fused q/k/v projection hands over
+    k, v = _rand((B, L, C), dtype, gen, 1.5).cuda(), _rand((B, L, C), dtype, gen).cuda()
+    rk, rv = _rand((B, N, Lr, C), dtype, gen, 1.5).cuda(), _rand((B, N, Lr, C), dtype, gen).cuda()
+    _, lse = ops.shared_attention(qs, k, v, rk, rv, heads=H, scale=0.125, include_self=True, return_lse=True, q_prescaled=True)
+    m_presc = ops.attn_segment_mass(qs, k, rk, lse, heads=H, scale=0.125, include_self=True, q_prescaled=True)
+    m_plain = ops.attn_segment_mass(qs, k, rk, lse, heads=H, scale=0.6931471805599453, include_self=True)
+    assert float((m_presc - m_plain).abs().max()) <= 1e-4
+    _, p_ref = O.shared_attention_np(_np64(qs), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.6931471805599453, False, True, return_probs=True)
+    edges = [0, L] + [L + (n + 1) * Lr for n in range(N)]
+    m_ref = np.stack([p_ref[..., a:b].sum(-1) for a, b in zip(edges[:-1], edges[1:])], axis=-1)
+    assert np.abs(m_presc.cpu().numpy() - m_ref).max() <= 2e-3
+    # and the dump itself accepts the flag (same expression with the factor 1)
+    p1 = ops.attn_probs(qs, k, rk, lse, heads=H, scale=0.125, include_self=True, q_prescaled=True)
+    assert np.abs(p1.float().cpu().numpy() - p_ref).max() <= TOL[dtype]

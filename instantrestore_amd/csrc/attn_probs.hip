@@ -26,8 +26,6 @@
 // attn_segment_mass (round 5, opt-in): mass[b,h,i,s] = sum of the probabilities of row i over segment s
 // ([self?] ++ ref 0 ++ ...), fp32 - what gradio_demo.py:119-127 reduces the 6.7 GB tensor to.  Same recompute, no big
 // tensor: bound by the exponentials (B*H*L*Lkv of them), not by memory.
-#include <type_traits>
-
 #include "ir_common.h"
 #include "ir_kernels.h"
 
@@ -57,12 +55,8 @@ static __device__ __forceinline__ unsigned pack2(float a, float b) {
   return __builtin_bit_cast(unsigned, v);
 }
 
-// PRESC (mass kernel only; IR_FLAG_Q_PRESCALED): q holds Q * scale * log2(e), the scores leave the matrix pipe as exponents, and
-// minus the row's LSE rides in on the C operand of a block's first MFMA (the 64-row attention kernel's trick): exp2 applies
-// to the MFMA result as it is - 64 multiply-adds fewer per wave and tile of a kernel that is bound by its vector instructions.
-template <typename T, int NQ, int NK, bool MASS, bool PRESC = false>
+template <typename T, int NQ, int NK, bool MASS>
 __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKParams p, const ProbsPlan pl, float* __restrict__ mass) {
-  static_assert(!PRESC || MASS, "the dump kernels keep one expression (bit-identical to each other)");
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
   constexpr int ROWS = 32 * NQ;                   // query rows per wave
@@ -144,41 +138,17 @@ __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKPa
   float msum[NQ];
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) msum[qi] = 0.f;
-  f32x16 nm[PRESC ? NQ : 1];   // PRESC: minus the row's LSE (exp2 domain) in all 16 registers: the C operand of a block's first MFMA
-  if constexpr (PRESC) {
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) nm[qi][r] = -lse2[qi];
-  }
 
   for (int j = j_begin; j < j_end; j += STEP) {
 #pragma unroll
     for (int kblk = 0; kblk < NK; ++kblk) {
       f32x16 sc[NQ];
-      if constexpr (PRESC) {
-        // spelled in asm: through the builtin hipcc takes the tied (dst = C) form and first copies the 16-register block
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-          if (std::is_same<T, __bf16>::value) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sc[qi]) : "v"(kf[kblk][0]), "v"(qf[qi][0]), "v"(nm[qi]));
-          else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(sc[qi]) : "v"(kf[kblk][0]), "v"(qf[qi][0]), "v"(nm[qi]));
-        }
-        // (the hazard recogniser cannot see the asm MFMAs: pad their results' way to the accumulating MFMAs by hand)
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+      for (int qi = 0; qi < NQ; ++qi) {
 #pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-          asm volatile("" : "+v"(sc[qi]));
+        for (int r = 0; r < 16; ++r) sc[qi][r] = 0.f;
 #pragma unroll
-          for (int ks = 1; ks < 4; ++ks) sc[qi] = Tr::mfma(kf[kblk][ks], qf[qi][ks], sc[qi]);
-        }
-      } else {
-#pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) sc[qi][r] = 0.f;
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) sc[qi] = Tr::mfma(kf[kblk][ks], qf[qi][ks], sc[qi]);
-        }
+        for (int ks = 0; ks < 4; ++ks) sc[qi] = Tr::mfma(kf[kblk][ks], qf[qi][ks], sc[qi]);
       }
       // the block's fragments are dead: the next step's arrive in the same registers while this step's exponentials run
       // (clamped past the end of the segment: always a valid address)
@@ -188,14 +158,13 @@ __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKPa
         // sc[qi][r] = <K[j + 32 kblk + 16 hi + r], Q[q0 + 32 qi + lq]>
         if constexpr (MASS) {
           const int kfirst = j + 32 * kblk + 16 * hi;
-          auto expo = [&](int r) { return PRESC ? fast_exp2(sc[qi][r]) : fast_exp2(__builtin_fmaf(sc[qi][r], p.scale_log2, -lse2[qi])); };
           if (j + STEP <= j_end) {   // wave-uniform: whole steps need no key mask
 #pragma unroll
-            for (int r = 0; r < 16; ++r) msum[qi] += expo(r);
+            for (int r = 0; r < 16; ++r) msum[qi] += fast_exp2(__builtin_fmaf(sc[qi][r], p.scale_log2, -lse2[qi]));
           } else {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float e = expo(r);
+              const float e = fast_exp2(__builtin_fmaf(sc[qi][r], p.scale_log2, -lse2[qi]));
               msum[qi] += (kfirst + r < j_end) ? e : 0.f;
             }
           }
@@ -407,16 +376,6 @@ hipError_t ir_launch_attn_segment_mass(const AttnKParams& p, int dtype, float* m
   const ProbsPlan pl = make_plan(p, PW * (nq2 ? 64 : 32), 64, true);   // whole segments: one writer per (row, segment), no reduction through memory
   if (pl.items <= 0) return hipErrorInvalidValue;
   const dim3 grid(pl.items), block(PW * 64);
-  if (p.q_prescaled) {   // IR_FLAG_Q_PRESCALED: the exponent-domain form
-    if (dtype == 1) {
-      if (nq2) hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 2, 2, true, true>), grid, block, 0, s, p, pl, mass);
-      else hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 1, 2, true, true>), grid, block, 0, s, p, pl, mass);
-    } else {
-      if (nq2) hipLaunchKernelGGL((attn_probs_lines_kernel<_Float16, 2, 2, true, true>), grid, block, 0, s, p, pl, mass);
-      else hipLaunchKernelGGL((attn_probs_lines_kernel<_Float16, 1, 2, true, true>), grid, block, 0, s, p, pl, mass);
-    }
-    return hipGetLastError();
-  }
   if (dtype == 1) {
     if (nq2) hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 2, 2, true>), grid, block, 0, s, p, pl, mass);
     else hipLaunchKernelGGL((attn_probs_lines_kernel<__bf16, 1, 2, true>), grid, block, 0, s, p, pl, mass);

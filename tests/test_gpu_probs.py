@@ -253,9 +253,11 @@ def test_randomised_shapes_line_kernels_equal_the_generic_kernel(ops):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 2, 72, 3, 40), (1, 2, 300, 2, 136), (1, 1, 1024, 4, 1024)], ids=["L72", "L300", "L1024"])
 def test_segment_mass_with_prescaled_q(ops, dtype, shape):
-    """IR_FLAG_Q_PRESCALED form of the mass kernel (minus the LSE through the MFMA C operand, no multiply-add per score): the
-    same numbers as the plain form on the same pre-scaled q (scale = ln 2 turns its exponents back into logits), and the
-    float64 block sums of softmax(q' k^T ln 2)"""
+    """IR_FLAG_Q_PRESCALED on the dump entry points (q holds Q * scale * log2(e): its products with k ARE the exponents, `scale`
+    stays the unit of the LSE): the same numbers as the unflagged call with scale = ln 2 on the same pre-scaled q, and the
+    float64 block sums of softmax(q' k^T ln 2).  (An exponent-domain form of the mass kernel - minus the LSE through the MFMA
+    C operand, no multiply-add per score - was built and measured SLOWER, 0.853 vs 0.810 ms at the cfg-2 top layer: the
+    16-register C blocks cost a wave of occupancy; not kept, NOTES 11.1.)"""
     B, H, L, N, Lr = shape
     C = H * 64
     gen = torch.Generator().manual_seed(11)

@@ -166,3 +166,39 @@ def test_randomised_valid_counts_equal_the_walk(ops):
         assert torch.isfinite(a.float()).all(), what
         assert float((a.float() - b.float()).abs().max()) <= bound, what
         assert float((lse_a - lse_b).abs().max()) <= 2e-3, what
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["gemm_partials", "standalone_statistics"])
+def test_two_unet_host_with_zero_filled_references_statistics_and_counts(fused):
+    """the whole plugin surface on the topology host: reference UNet -> harvest(with_stats, with_valid) with valid = [2, 1] of 3
+    (zero fill in place, statistics of the zeroed references invalidated) -> main UNet with 'ref_stats' and 'ref_valid' against the
+    same call without 'ref_valid' (the kernels walk the zero tiles): same latents within twice the bf16 tolerance.  Both forms of
+    the content statistics: the q/k/v GEMM's partials (round 4) and the standalone pass."""
+    from types import SimpleNamespace
+    from face_replace.models.attn_processors import register_attention_processor, register_attention_processor_kv_unet
+    from instantrestore_amd import attn_processors as ap
+    from instantrestore_amd.kv_harvest import get_conditioning_keys_values
+    from instantrestore_amd.unet_host import AttnTopologyUNet
+    import __graft_entry__ as ge
+    cfg = SimpleNamespace(use_adain=True, train_input=True, condition_on_face_embeds=False)
+    kv_unet, unet = AttnTopologyUNet(seed=5).to("cuda"), AttnTopologyUNet(seed=6).to("cuda")
+    ge.register_attention_processor_kv_unet_default(kv_unet, cfg)
+    register_attention_processor_kv_unet(kv_unet)
+    register_attention_processor(unet, cfg)
+    B, N, S = 2, 3, 32                                            # 32 x 32 latent: token axes of 16 / 64 / 256 ... per class
+    text = torch.randn(1, 77, 1024, device="cuda")
+    x = torch.randn(B, 4, S, S, device="cuda")
+    ap.FUSED_STATS = fused
+    try:
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            keys, vals, stats, valid = get_conditioning_keys_values(kv_unet, torch.randn(B * N, 4, S, S, device="cuda"), None,
+                                                                    text.repeat(B * N, 1, 1), N, [2, 1], with_stats=True, with_valid=True)
+            assert valid.tolist() == [2, 1] and all(float(k[1, 1:].abs().max()) == 0.0 for k in keys)
+            kw = {"ref_keys": keys, "ref_values": vals, "ref_stats": stats}
+            a = unet(x, None, encoder_hidden_states=text.repeat(B, 1, 1), cross_attention_kwargs=dict(kw, ref_valid=valid)).sample
+            b = unet(x, None, encoder_hidden_states=text.repeat(B, 1, 1), cross_attention_kwargs=kw).sample
+    finally:
+        ap.FUSED_STATS = True
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all()
+    assert float((a.float() - b.float()).abs().max()) <= 2 * 8e-3 * max(1.0, float(b.float().abs().max()))

@@ -139,3 +139,23 @@ def test_two_rank_uint8_image_path():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in results), results
+
+
+def test_cfg3_partition_eight_ranks_sixty_four_identities():
+    """cfg 3 (BASELINE.json: batch = 64 identities sharded over 8 MI355X): the same scatter -> step -> gather with world size 8 and
+    64 identities, eight gloo processes on this CPU - every rank gets exactly 8 contiguous identities (contiguous
+    B / G split, one peer per link, no data-path collective), rank 0 gets all 64 outputs back in order.  What the 8-GPU node
+    adds is RCCL over xGMI under the same calls; no such node has been available."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world, total = 8, 64
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    assert sorted(r for r, _ in results) == list(range(world))
+    assert all(ok for _, ok in results), results
+    assert shard_sizes(total, world) == [8] * 8

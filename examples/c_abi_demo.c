@@ -112,5 +112,25 @@ int main(void) {
   }
   const double bound = 8e-3 * (maxref > 1 ? maxref : 1);
   printf("max|err| %.3e (bound %.3e, max|ref| %.3f): %s\n", maxerr, bound, maxref, maxerr <= bound ? "OK" : "FAIL");
-  return maxerr <= bound ? 0 : 4;
+  if (maxerr > bound) return 4;
+
+  /* ABI v8: the per-reference attention mass gradio_demo.py:119-127 reduces attention_probs to, without the (B,H,L,Lkv)
+     tensor: the same call once more for its LSE, then ir_attn_segment_mass -> fp32 (B, H, L, 1 + N); every row sums to 1 */
+  float *dlse, *dmass;
+  const size_t nm = (size_t)B * H * L * (1 + N);
+  CHECK_HIP(hipMalloc((void**)&dlse, sizeof(float) * B * H * L)); CHECK_HIP(hipMalloc((void**)&dmass, sizeof(float) * nm));
+  a.lse = dlse;
+  CHECK_IR(ir_shared_attn_fwd(&a, NULL));
+  CHECK_IR(ir_attn_segment_mass(&a, dmass, NULL));
+  CHECK_HIP(hipDeviceSynchronize());
+  float* mass = malloc(sizeof(float) * nm);
+  CHECK_HIP(hipMemcpy(mass, dmass, sizeof(float) * nm, hipMemcpyDeviceToHost));
+  double worst = 0;
+  for (size_t r = 0; r < (size_t)B * H * L; ++r) {
+    double sum = 0;
+    for (int s2 = 0; s2 <= N; ++s2) sum += mass[r * (1 + N) + s2];
+    if (fabs(sum - 1.0) > worst) worst = fabs(sum - 1.0);
+  }
+  printf("segment mass: max |row sum - 1| %.3e: %s\n", worst, worst <= 2e-3 ? "OK" : "FAIL");
+  return worst <= 2e-3 ? 0 : 5;
 }

@@ -69,6 +69,45 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
         _lib.check(-1, "demo")
 
 
+def test_abi_v8_entry_points_validate_without_a_gpu():
+    """round 5 (ABI v8): the dump kernels named by the caller, the per-segment mass and the valid-counts field refuse bad
+    arguments before any launch; the automatic tile choice takes the split-K tile exactly where it was measured ahead"""
+    from instantrestore_amd import _lib
+    lib = _lib.lib()
+    a = _lib.SharedAttnArgs()
+    a.struct_size = C.sizeof(a)
+    a.dtype, a.batch, a.heads, a.len_q, a.len_self, a.flags, a.scale = 1, 1, 1, 64, 64, 1, 0.125
+    buf = (C.c_char * 65536)()
+    ptr = C.cast(C.byref(buf, 64 - C.addressof(buf) % 64), C.c_void_p)        # a 64-byte aligned host address (never dereferenced)
+    a.q = a.k_self = a.v_self = ptr
+    a.q_sb = a.ks_sb = a.vs_sb = 64 * 64
+    a.q_sl = a.ks_sl = a.vs_sl = 64
+    a.q_sh = a.ks_sh = a.vs_sh = 64
+    assert lib.ir_attn_probs_ex(C.byref(a), None, 0, None) == -1 and b"probs/lse" in lib.ir_last_error_string()
+    a.lse = ptr
+    assert lib.ir_attn_probs_ex(C.byref(a), ptr, 7, None) == -2                                # unknown kernel id
+    assert lib.ir_attn_probs_ex(C.byref(a), ptr, -1, None) == -2
+    a.len_self = 60                                                                             # 60 keys: rows of P not 16-byte aligned
+    assert lib.ir_attn_probs_ex(C.byref(a), ptr, 2, None) == -2 and b"multiples of 8" in lib.ir_last_error_string()
+    assert lib.ir_attn_segment_mass(C.byref(a), None, None) == -1
+    a.len_self = 64
+    a.n_refs, a.len_ref = 2, 64
+    a.k_ref = a.v_ref = ptr
+    a.kr_sb = a.vr_sb = 2 * 64 * 64
+    a.kr_sn = a.vr_sn = 64 * 64
+    a.kr_sl = a.vr_sl = 64
+    a.kr_sh = a.vr_sh = 64
+    a.out = ptr
+    a.o_sb, a.o_sl, a.o_sh = 64 * 64, 64, 64
+    a.valid_refs = C.cast(C.c_void_p(ptr.value + 2), C.c_void_p)                                # not 4-byte aligned
+    assert lib.ir_shared_attn_fwd(C.byref(a), None) == -2 and b"valid_refs" in lib.ir_last_error_string()
+    # tile picker: M = 2048 x N = 1280 x K = 1280 (160 tiles of 128 x 128 on 256 CUs) takes the split-K tile (id 9); the same
+    # rows at N = 3840 (480 tiles) and the K = 640 shapes do not
+    assert lib.ir_linear_kernel_for(2048, 1280, 1280, 1) == 9
+    assert lib.ir_linear_kernel_for(2048, 3840, 1280, 0) == 3 and lib.ir_linear_kernel_for(8192, 640, 640, 1) == 3
+    assert lib.ir_linear_kernel_for(8192, 3840, 1280, 0) == 8
+
+
 def test_statistics_tail_entry_points_validate_without_a_gpu():
     """ABI 6 (round 4): the q/k/v projection that leaves the AdaIN token statistics behind and the merges of its partials -
     shape rules answered and bad arguments rejected before any launch"""

@@ -628,7 +628,8 @@ def extra_probs_dump(layers, B, N, train_input, dtype, dev):
     """The dump path (attn_processors.py:258-261; what gradio_demo.py:108-109 turns on for every request): ``ir_attn_probs`` at
     the three layer classes of the config - HIP-event time per launch, GB/s of the H*L*Lkv*2 bytes it writes, and that rate as a
     fraction of the copy and fill rates measured HERE, now, on this box (a 1 GiB -> 1 GiB copy, a 1 GiB fill).  Plus the opt-in
-    per-segment mass (``ir_attn_segment_mass``): what a consumer that only ranks the references needs, without the tensor."""
+    per-segment mass: what a consumer that only ranks the references needs, without the tensor - as a second pass
+    (``ir_attn_segment_mass``) and as a by-product of the attention launch itself (ABI v9 ``seg_mass``)."""
     from instantrestore_amd import ops as _o
 
     def timed(fn, iters):
@@ -668,10 +669,14 @@ def extra_probs_dump(layers, B, N, train_input, dtype, dev):
         ms = timed(lambda: _o.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=bool(t)), iters)
         ms_old = timed(lambda: _o.attn_probs(q, k, rk, lse, heads=H, scale=0.125, include_self=bool(t), kernel="generic"), iters)
         ms_mass = timed(lambda: _o.attn_segment_mass(q, k, rk, lse, heads=H, scale=0.125, include_self=bool(t)), iters)
+        # the masses as a by-product of the attention launch (ABI v9 seg_mass) against the launch alone
+        ms_attn = timed(lambda: _o.shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, include_self=bool(t)), 10)
+        ms_attn_mass = timed(lambda: _o.shared_attention(q, k, v, rk, rv, heads=H, scale=0.125, include_self=bool(t), return_mass=True), 10)
         gbs = nbytes / ms / 1e6
         per_class.append({"L": L, "H": H, "Lkv": (N + t) * L, "gb_written": round(nbytes / 1e9, 3), "ms": round(ms, 4), "gb_per_s": round(gbs, 1),
                           "frac_of_copy_rate": round(gbs / copy_gbs, 3), "frac_of_fill_rate": round(gbs / fill_gbs, 3),
-                          "ms_round1_kernel_2byte_stores": round(ms_old, 4), "ms_segment_mass_only": round(ms_mass, 4)})
+                          "ms_round1_kernel_2byte_stores": round(ms_old, 4), "ms_segment_mass_second_pass": round(ms_mass, 4),
+                          "ms_attention": round(ms_attn, 4), "ms_attention_with_segment_mass_by_product": round(ms_attn_mass, 4)})
         total_ms += 3 * ms
         total_bytes += 3 * nbytes
         del q, k, v, rk, rv, lse

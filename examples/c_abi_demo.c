@@ -114,23 +114,33 @@ int main(void) {
   printf("max|err| %.3e (bound %.3e, max|ref| %.3f): %s\n", maxerr, bound, maxref, maxerr <= bound ? "OK" : "FAIL");
   if (maxerr > bound) return 4;
 
-  /* ABI v8: the per-reference attention mass gradio_demo.py:119-127 reduces attention_probs to, without the (B,H,L,Lkv)
-     tensor: the same call once more for its LSE, then ir_attn_segment_mass -> fp32 (B, H, L, 1 + N); every row sums to 1 */
-  float *dlse, *dmass;
+  /* The per-reference attention mass gradio_demo.py:119-127 reduces attention_probs to, without the (B,H,L,Lkv) tensor:
+     ABI v9 - a BY-PRODUCT of the attention call itself (args.seg_mass -> fp32 (B, H, L, 1 + N); every row sums to 1);
+     ABI v8 - a second pass over Q and K from the call's LSE (ir_attn_segment_mass), for callers that only kept the LSE */
+  float *dlse, *dmass, *dmass2;
   const size_t nm = (size_t)B * H * L * (1 + N);
   CHECK_HIP(hipMalloc((void**)&dlse, sizeof(float) * B * H * L)); CHECK_HIP(hipMalloc((void**)&dmass, sizeof(float) * nm));
+  CHECK_HIP(hipMalloc((void**)&dmass2, sizeof(float) * nm));
   a.lse = dlse;
+  a.seg_mass = dmass;
   CHECK_IR(ir_shared_attn_fwd(&a, NULL));
-  CHECK_IR(ir_attn_segment_mass(&a, dmass, NULL));
+  a.seg_mass = NULL;
+  CHECK_IR(ir_attn_segment_mass(&a, dmass2, NULL));
   CHECK_HIP(hipDeviceSynchronize());
   float* mass = malloc(sizeof(float) * nm);
+  float* mass2 = malloc(sizeof(float) * nm);
   CHECK_HIP(hipMemcpy(mass, dmass, sizeof(float) * nm, hipMemcpyDeviceToHost));
-  double worst = 0;
+  CHECK_HIP(hipMemcpy(mass2, dmass2, sizeof(float) * nm, hipMemcpyDeviceToHost));
+  double worst = 0, apart = 0;
   for (size_t r = 0; r < (size_t)B * H * L; ++r) {
     double sum = 0;
-    for (int s2 = 0; s2 <= N; ++s2) sum += mass[r * (1 + N) + s2];
+    for (int s2 = 0; s2 <= N; ++s2) {
+      sum += mass[r * (1 + N) + s2];
+      if (fabs(mass[r * (1 + N) + s2] - mass2[r * (1 + N) + s2]) > apart) apart = fabs(mass[r * (1 + N) + s2] - mass2[r * (1 + N) + s2]);
+    }
     if (fabs(sum - 1.0) > worst) worst = fabs(sum - 1.0);
   }
-  printf("segment mass: max |row sum - 1| %.3e: %s\n", worst, worst <= 2e-3 ? "OK" : "FAIL");
-  return worst <= 2e-3 ? 0 : 5;
+  const int ok = worst <= 1e-5 && apart <= 1e-4;
+  printf("segment mass (by-product of the call): max |row sum - 1| %.3e, max |by-product - second pass| %.3e: %s\n", worst, apart, ok ? "OK" : "FAIL");
+  return ok ? 0 : 5;
 }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IR_ABI_VERSION 8
+#define IR_ABI_VERSION 9
 #define IR_HEAD_DIM 64
 
 typedef enum ir_status {
@@ -117,6 +117,14 @@ typedef struct ir_shared_attn_args {
                                key is exactly 0, every value row is 0, or the AdaIN shift b when an affine is given) instead of
                                walking their tiles.  Same result as with NULL: zeroed, not masked - the tokens keep their exp(0)
                                weight.  NULL = every reference is walked. */
+  float* seg_mass;          /* ABI v9, optional output: fp32 (B, H, len_q, S) contiguous, S = (INCLUDE_SELF ? 1 : 0) + n_refs - the
+                               attention mass of every K/V segment, mass[b,h,i,s] = sum over the keys j of segment s of
+                               softmax_j(scale * <q_i, k_j>), as a BY-PRODUCT of this launch: the kernels hold the row sums at
+                               every segment boundary anyway and store the cumulative log-sum-exp there; a row-sized finishing
+                               kernel on the same stream turns them into masses (the S masses of a row sum to exactly 1).  What
+                               gradio_demo.py:119-127 reduces attention_probs to, with no second pass over Q and K
+                               (ir_attn_segment_mass is that second pass, for callers that only kept the LSE).  Taken as
+                               differences of cumulative sums: absolute accuracy ~1e-6, not relative.  NULL = off. */
 } ir_shared_attn_args;
 
 /* values of ir_shared_attn_args.tuning (csrc/shared_attn_fwd.hip lists what each one is) */

@@ -13,7 +13,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # IR_LIB_PATH: load an alternative build of the same ABI (compiler-flag A/B experiments)
 LIB_PATH = os.environ.get("IR_LIB_PATH") or os.path.join(_HERE, "libinstantrestore_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 IR_DTYPE_F16, IR_DTYPE_BF16 = 0, 1
 IR_FLAG_INCLUDE_SELF, IR_FLAG_Q_PRESCALED, IR_FLAG_OUT_F32 = 1, 2, 4
@@ -31,7 +31,7 @@ class SharedAttnArgs(C.Structure):
         + [(n, i64) for n in ("q_sb", "q_sl", "q_sh", "ks_sb", "ks_sl", "ks_sh", "vs_sb", "vs_sl", "vs_sh",
                               "kr_sb", "kr_sn", "kr_sl", "kr_sh", "vr_sb", "vr_sn", "vr_sl", "vr_sh",
                               "o_sb", "o_sl", "o_sh")]
-        + [("workspace", vp), ("workspace_bytes", C.c_uint64), ("tuning", i32), ("reserved", i32), ("valid_refs", vp)]
+        + [("workspace", vp), ("workspace_bytes", C.c_uint64), ("tuning", i32), ("reserved", i32), ("valid_refs", vp), ("seg_mass", vp)]
     )
 
 

@@ -394,7 +394,7 @@ class SharedAttnProcessor(nn.Module):
         # opt-in (round 5; a plain attribute like ``AttnProcessor.record_events``, the constructor stays the reference's): when set,
         # every call also leaves ``attention_mass`` - fp32 (B, H, L, [self?] + N), the attention mass per K/V segment - which is what
         # gradio_demo.py:119-127 reduces ``attention_probs`` to (``probs[..., attn_size*idx : attn_size*(idx+1)].sum(-1)``), without
-        # the (B, H, L, Lkv) tensor (``ir_attn_segment_mass``).  Independent of ``save_self_attentions``, whose meaning is unchanged.
+        # the (B, H, L, Lkv) tensor and without a second pass (``ir_shared_attn_args.seg_mass``, ABI v9).  Independent of ``save_self_attentions``, whose meaning is unchanged.
         self.save_attention_mass = False
         self.attention_mass = None
 
@@ -458,13 +458,13 @@ class SharedAttnProcessor(nn.Module):
         kw = {"q_prescaled": True} if presc else {}
         if shared and ref_valid is not None:
             kw["valid_refs"] = ref_valid
+        # the masses are a by-product of the attention launch itself (ABI v9 ``seg_mass``: the kernels hold the row sums at every
+        # segment boundary): no second pass over Q and K
         res = _ops.shared_attention(query, key, value, ref_k, ref_v, heads=attn.heads, scale=attn.scale,
-                                    include_self=include_self, adain=affine, return_lse=want_probs or want_mass, **kw)
+                                    include_self=include_self, adain=affine, return_lse=want_probs, return_mass=want_mass, **kw)
         if want_mass:
-            self.attention_mass = _ops.attn_segment_mass(query, key, ref_k, res[1], heads=attn.heads, scale=attn.scale,
-                                                         include_self=include_self, q_prescaled=bool(presc))
-            if not want_probs:
-                res = res[0]
+            self.attention_mass = res[-1]
+            res = res[:-1] if want_probs else res[0]
         if want_probs:
             tokens, lse = res
             # (B, H, L, Lkv), columns [self?] ++ ref0 ++ ... ++ refN-1, in the compute dtype.  A pre-scaled query

@@ -44,6 +44,7 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   if ((a->adain_a == nullptr) != (a->adain_b == nullptr)) return fail(IR_ERR_INVALID_ARG, "adain_a and adain_b must both be set or both be NULL");
   if (a->adain_a != nullptr && a->n_refs == 0) return fail(IR_ERR_INVALID_ARG, "AdaIN affine without references");
   if (a->valid_refs != nullptr && (reinterpret_cast<uintptr_t>(a->valid_refs) & 3u) != 0) return fail(IR_ERR_UNSUPPORTED, "valid_refs must be 4-byte aligned");
+  if (a->seg_mass != nullptr && (reinterpret_cast<uintptr_t>(a->seg_mass) & 3u) != 0) return fail(IR_ERR_UNSUPPORTED, "seg_mass must be 4-byte aligned");
   const void* ptrs[] = {a->q, a->k_self, a->v_self, a->k_ref, a->v_ref, a->out, a->adain_a, a->adain_b};
   for (const void* q : ptrs)
     if (q != nullptr && !aligned16(q)) return fail(IR_ERR_UNSUPPORTED, "pointer %p is not 16-byte aligned", q);
@@ -57,6 +58,8 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->q = a->q; p->k_self = a->k_self; p->v_self = a->v_self; p->k_ref = a->k_ref; p->v_ref = a->v_ref;
   p->aa = a->adain_a; p->ab = a->adain_b; p->out = a->out; p->lse = a->lse;
   p->valid = a->n_refs > 0 ? a->valid_refs : nullptr;
+  p->seg_cum = need_out ? a->seg_mass : nullptr;   // a by-product of the forward launch only (ir_attn_probs / _segment_mass ignore it)
+  p->nseg_out = (inc ? 1 : 0) + a->n_refs;
   p->q_sb = a->q_sb; p->q_sl = a->q_sl; p->q_sh = a->q_sh;
   p->ks_sb = a->ks_sb; p->ks_sl = a->ks_sl; p->ks_sh = a->ks_sh;
   p->vs_sb = a->vs_sb; p->vs_sl = a->vs_sl; p->vs_sh = a->vs_sh;

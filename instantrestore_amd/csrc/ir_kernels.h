@@ -50,6 +50,14 @@ struct AttnKParams {
   int sk_ix;          // ceil(sk_items / 8)
   int sk_full;
   int sk_k;
+  // ABI v9 (ir_shared_attn_args.seg_mass): attention mass per K/V segment as a BY-PRODUCT of the forward kernels.  At every segment
+  // boundary of its K/V walk a kernel already holds the row sums (the AdaIN fold needs them); it stores the CUMULATIVE log-sum-exp
+  // through segment s - a number that does not depend on the running reference - into seg_cum[b,h,row,s] (natural log; pieces of a
+  // split item: log2 units into ws_cum, merged by the combine kernel), and seg_mass_finish_kernel turns the S cumulative values of
+  // a row into S masses in place.  nullptr: off (nothing but one uniform test per SEGMENT, none per tile).
+  float* seg_cum;     // (B, H, Lq, nseg_out) fp32 or nullptr
+  float* ws_cum;      // [piece][QB rows][nseg_out]
+  int nseg_out;       // include_self + N
 };
 
 struct AdainKParams {
@@ -100,6 +108,7 @@ hipError_t ir_launch_shared_attn_fwd_w64_abl(const AttnKParams& p, int dtype, in
 int ir_w64_abl_count(void);
 int ir_w64_abl_mask(int index);
 #endif
+hipError_t ir_launch_seg_mass_finish(const AttnKParams& p, hipStream_t s);   // cumulative log-sum-exp -> masses, in place
 bool ir_attn_default_is_w64(const AttnKParams& p);
 bool ir_attn_variant_available(int variant);
 

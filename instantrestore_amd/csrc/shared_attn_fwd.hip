@@ -439,8 +439,45 @@ bool ir_attn_default_is_w64(const AttnKParams& p) {
   return p.Lq >= 4096 && (items512 >= 256 || p.ntiles >= 128);
 }
 
+// ABI v9 (seg_mass): the forward kernels left, per row, the cumulative log-sum-exp c_0 <= c_1 <= ... <= c_{S-1} (= the row's LSE)
+// through each K/V segment; the mass of segment s is exp(c_s - c_{S-1}) - exp(c_{s-1} - c_{S-1}).  In place, one thread per row;
+// the masses of a row telescope to exactly 1.
+__global__ void __launch_bounds__(256) seg_mass_finish_kernel(float* __restrict__ cum, long rows, int S) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  float* c = cum + r * S;
+  const float tot = c[S - 1];
+  float prev = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float e = s == S - 1 ? 1.f : __expf(c[s] - tot);
+    c[s] = e - prev;
+    prev = e;
+  }
+}
+
+hipError_t ir_launch_seg_mass_finish(const AttnKParams& p, hipStream_t s) {
+  const long rows = (long)p.B * p.H * p.Lq;
+  if (rows == 0 || p.nseg_out <= 0) return hipSuccess;
+  hipLaunchKernelGGL(seg_mass_finish_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, p.seg_cum, rows, p.nseg_out);
+  return hipGetLastError();
+}
+
+static hipError_t launch_attn_kernel(const AttnKParams& p, int dtype, int variant, hipStream_t s);
+
 hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
   if (!ir_attn_variant_available(variant)) return hipErrorInvalidValue;
+  if (p.seg_cum != nullptr) {
+    // by-product of the 64-row and the pipelined 32-row kernels (every product kernel); the development-only experiments never learned it
+    // (the 8-wave 64-row kernel and the 32-row kernel's two default forms carry the MASS instantiation: tuning 0, 11, 13, 14)
+    const int b0 = variant & 31;
+    if ((variant >> 5) != 0 || !(b0 == 0 || b0 == 11 || b0 == 13 || b0 == 14)) return hipErrorInvalidValue;
+  }
+  const hipError_t e = launch_attn_kernel(p, dtype, variant, s);
+  if (e != hipSuccess || p.seg_cum == nullptr) return e;
+  return ir_launch_seg_mass_finish(p, s);
+}
+
+static hipError_t launch_attn_kernel(const AttnKParams& p, int dtype, int variant, hipStream_t s) {
 #ifdef IR_ABLATIONS
   {   // the experiments that never learned IR_FLAG_OUT_F32 would write 16-bit data into an fp32 buffer
     const int b0 = variant & 31;

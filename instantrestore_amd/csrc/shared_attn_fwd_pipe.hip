@@ -31,7 +31,9 @@ constexpr int TILE_BYTES = KVB * 64 * 2;  // 8 KiB
 
 // ABL (timing experiments only, WRONG results): 1 = no barrier, 2 = no LDS staging writes,
 // 4 = no global loads, 8 = no exp/pack VALU, 16 = no LDS fragment reads
-template <typename T, int NW, bool FOLD, int ABL = 0>
+// MASS (ABI v9 seg_mass): also store the cumulative log-sum-exp at every segment boundary - a separate instantiation of the two
+// default forms, launched only when the caller asks for the masses
+template <typename T, int NW, bool FOLD, int ABL = 0, bool MASS = false>
 __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) shared_attn_fwd_pipe_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
@@ -276,6 +278,27 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     load_kf(kf0, kf1, kslot);
     qk_mfma(s0, s1, kf0, kf1);
   };
+  // ABI v9 (seg_mass): cumulative log-sum-exp through segment s of this lane pair's row (log2 units) -> seg_cum, or this
+  // piece's slot of ws_cum (shared_attn_fwd_w64.hip has the scheme).  The parameters are read from the kernel-argument segment
+  // through a pointer the compiler cannot see through, so nothing of this stays in registers across the tile loop.
+  typedef const __attribute__((address_space(4))) AttnKParams* KArgs;
+  auto cold = [&]() -> KArgs { KArgs q = (KArgs)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; };
+  auto cum_store = [&](int s, float v2) {
+    const KArgs c = cold();
+    if (hi != 0) return;
+    if (npiece > 1) {
+      const int64_t prow = ((int64_t)((xcd * (c->sk_ix - c->sk_full) + (item_local - c->sk_full)) * npiece + piece)) * QB + wid * 32 + lq;
+      c->ws_cum[prow * c->nseg_out + s] = v2;
+    } else if (qrow < c->Lq) {
+      c->seg_cum[(((int64_t)b * c->H + h) * c->Lq + qrow) * c->nseg_out + s] = v2 * 0.69314718f;
+    }
+  };
+  auto row_sum_now = [&]() {
+    const float ls = (la[0] + la[1]) + (lb[0] + lb[1]);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  };
+  auto ref_log2 = [&]() { return PRESC ? m_run : m_run * c2; };
   // Fold the current segment's accumulators into the lazily scaled LDS total:
   //   total = total * 2^((m_ot - m_run) c) + O_seg o a_seg + rowsum(P_seg) * b_seg
   // (a = 1, b = 0 for the self segment).  Linear in the keys, so folding a PART of a segment (a
@@ -289,6 +312,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     const float f = fast_exp2(PRESC ? (m_ot - m_run) : (m_ot - m_run) * c2);  // m_ot = -inf the first time: f = 0
     l_tot = l_tot * f + lseg;
     m_ot = m_run;
+    if (MASS) cum_store(cseg, ref_log2() + __log2f(l_tot));   // l_tot: every segment so far, relative to m_run
     const bool is_ref = !(p.include_self && cseg == 0);
     const int n = cseg - p.include_self;
     const int64_t ao = ((int64_t)(b * p.N + (is_ref ? n : 0)) * p.H + h) * 64 + 4 * hi;
@@ -495,6 +519,7 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     // (5) segment boundary of this stream: fold the AdaIN affine into the LDS total
     if (++ct0 == c_ntile) {
       if (FOLD) fold_segment();
+      else if (MASS) cum_store(cseg, ref_log2() + __log2f(row_sum_now()));   // no fold: the sums run over all segments
       ct0 = 0;
       ++cseg;
       c_ntile = p.tiles_ref;
@@ -576,6 +601,12 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
 
   // ---- epilogue -----------------------------------------------------------------------------
   if (FOLD && ct0 != 0) fold_segment();  // a piece that stops inside a segment folds what it has
+  constexpr bool want_cum = MASS;
+  if (!FOLD && want_cum && ct0 != 0) cum_store(cseg, ref_log2() + __log2f(row_sum_now()));
+  const int s_next = cseg + (ct0 != 0 ? 1 : 0);   // first segment whose cumulative value this piece has not stored yet
+  if (want_cum && npiece > 1)
+    for (int s = 0; s < seg_b; ++s) cum_store(s, -INFINITY);   // segments before this piece's range
+  float l_pre = -1.f, pz_seg = 0.f;               // zero suffix: row sum before it (final frame), weight of one zero segment
   if (nref < p.N && piece == npiece - 1) {
     // zero-filled references in closed form (ABI v8): (N - nref) * Lr keys that all score exactly 0 and carry a zero value
     // row (with the fold: the AdaIN shift b).  The reference moves up to 0 if it was below; everything accumulated is
@@ -587,6 +618,9 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     const float alpha = fast_exp2(-up);
     m_run += PRESC ? up : up / c2;
     const float pz = fast_exp2(e - up) * (float)p.Lr;          // weight of ONE zero segment (Lr keys); bs below sums the segments' shifts
+    pz_seg = pz;
+    if (FOLD) l_pre = l_tot * alpha;
+    else if (want_cum) l_pre = row_sum_now() * alpha;
     if (FOLD) {
       l_tot = l_tot * alpha + pz * nz;
       m_ot = m_run;
@@ -620,6 +654,17 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     float ls = (la[0] + la[1]) + (lb[0] + lb[1]);
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
     l_fin = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
+  if (want_cum) {
+    // segments after the end of this piece's range: the piece's total - and, on the piece that owns the zero-filled suffix, the
+    // row sum before the suffix plus j zero segments
+    const KArgs c = cold();
+    const float lp = l_pre < 0.f ? l_fin : l_pre, mref = ref_log2();
+    const int sz = c->include_self + nref;
+    for (int s = s_next; s < c->nseg_out; ++s) {
+      const int j = s - sz + 1;
+      cum_store(s, mref + __log2f(lp + pz_seg * (float)(j > 0 ? j : 0)));
+    }
   }
   if (npiece > 1) {
     // partial result of a K/V-range piece: unnormalised O (fp32), raw max, row sum -> workspace
@@ -705,13 +750,25 @@ __global__ void __launch_bounds__(256) shared_attn_combine_kernel(const AttnKPar
   if (p.out_f32) *(f32x4*)((float*)p.out + off) = acc * inv;   // IR_FLAG_OUT_F32: the result before the 16-bit rounding
   else *(v4*)((T*)p.out + off) = __builtin_convertvector(acc * inv, v4);
   if (p.lse != nullptr && grp == 0) p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = M * p.scale + __logf(L);
+  if (p.seg_cum != nullptr) {
+    // ABI v9: a piece's entry s is the log-sum-exp (log2 units) of what ITS key range holds of segments 0 .. s (-inf before its
+    // range, its total after it): the item's cumulative value is their log-sum-exp, taken in the fixed piece order
+    for (int sg = grp; sg < p.nseg_out; sg += 16) {
+      float mx = -INFINITY;
+      for (int j = 0; j < p.sk_k; ++j) mx = fmaxf(mx, p.ws_cum[((base + j) * QB + row) * p.nseg_out + sg]);
+      float sum = 0.f;
+      for (int j = 0; j < p.sk_k; ++j) sum += fast_exp2(p.ws_cum[((base + j) * QB + row) * p.nseg_out + sg] - mx);
+      p.seg_cum[(((int64_t)b * p.H + h) * p.Lq + qrow) * p.nseg_out + sg] = mx == -INFINITY ? -INFINITY : (mx + __log2f(sum)) * 0.69314718f;
+    }
+  }
 }
 
 // Work plan: items = B*H*ceil(Lq/QB); every XCD owns ix = ceil(items/8) consecutive items and
 // has `slots_x` concurrently resident workgroups (CUs/8 * workgroups per CU).  Whole rounds run
 // full K/V ranges; the remainder items are cut into k pieces so the last round ends early.
-template <typename T, int NW, bool FOLD, int ABL = 0>
+template <typename T, int NW, bool FOLD, int ABL = 0, bool MASS = false>
 hipError_t launch(const AttnKParams& p0, hipStream_t s) {
+  if (!MASS && p0.seg_cum != nullptr) return hipErrorInvalidValue;   // seg_mass: the two default forms carry the MASS instantiation
   AttnKParams p = p0;
   constexpr int QB = NW * 32;
   p.nqb = (p.Lq + QB - 1) / QB;
@@ -722,7 +779,7 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   int rem = p.sk_ix - full;
   int k = 1;
   if (p.ws != nullptr && rem > 0) {
-    const size_t piece_bytes = (size_t)QB * 66 * sizeof(float);
+    const size_t piece_bytes = (size_t)QB * (66 + (p.seg_cum != nullptr ? p.nseg_out : 0)) * sizeof(float);
     // pieces of at least 8 tiles.  (Round 3 tried 5-tile pieces for the 16x16-token class - 320 items of 20 tiles on 512
     // slots, cut in three - to put two workgroups on every CU: 47 us against 37 us unsplit, profiles/r3_layer_classes_cfg2_presc.txt:
     // the prologue, the fp32 partials and the combine launch cost more than the idle slots.)
@@ -733,8 +790,9 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.sk_k = k;
   p.ws_o = p.ws;
   p.ws_ml = p.ws + (size_t)8 * rem * k * QB * 64;
+  p.ws_cum = p.ws_ml + (size_t)8 * rem * k * QB * 2;
   const int grid = 8 * (full + rem * k);
-  hipLaunchKernelGGL((shared_attn_fwd_pipe_kernel<T, NW, FOLD, ABL>), dim3(grid), dim3(NW * 64), 0, s, p);
+  hipLaunchKernelGGL((shared_attn_fwd_pipe_kernel<T, NW, FOLD, ABL, MASS>), dim3(grid), dim3(NW * 64), 0, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || k <= 1) return e;
   hipLaunchKernelGGL((shared_attn_combine_kernel<T, QB>), dim3(8 * rem, QB / 16), dim3(256), 0, s, p);
@@ -744,6 +802,11 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
 template <typename T>
 hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
   const bool fold = (p.aa != nullptr);
+  if (p.seg_cum != nullptr) {   // ABI v9 seg_mass: the two forms the default dispatch takes
+    if (nw == 11) return fold ? launch<T, 4, true, 128 | 1024 | 2048, true>(p, s) : launch<T, 4, false, 128 | 1024 | 2048, true>(p, s);
+    if (nw == 14) return fold ? launch<T, 4, true, 128 | 1024 | 4096, true>(p, s) : launch<T, 4, false, 128 | 1024 | 4096, true>(p, s);
+    return hipErrorInvalidValue;
+  }
 #ifdef IR_ABLATIONS
   if (nw == 8) return fold ? launch<T, 8, true>(p, s) : launch<T, 8, false>(p, s);
   if (nw == 6) return fold ? launch<T, 4, true, 64>(p, s) : launch<T, 4, false, 64>(p, s);  // LDS-DMA staging

@@ -44,7 +44,9 @@ struct RowBlock {
 //   4 Q fragments read from LDS once per tile instead of four times                      8 no exponentials
 //  16 no row sums (and no outgrown-reference check)                                      32 no fp32 -> 16-bit conversions
 constexpr int W64_ABL_NODMA = 1, W64_ABL_NOBAR = 2, W64_ABL_QREUSE = 4, W64_ABL_NOEXP = 8, W64_ABL_NOSUM = 16, W64_ABL_NOPACK = 32;
-template <typename T, bool FOLD, int NW = 4, bool QS = false, int ABL = 0>
+// MASS (ABI v9 seg_mass): also store the cumulative log-sum-exp at every segment boundary (a separate instantiation, launched
+// only when the caller asks for the masses: the default kernels' code is untouched by it).
+template <typename T, bool FOLD, int NW = 4, bool QS = false, int ABL = 0, bool MASS = false>
 __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const AttnKParams p) {
   using Tr = ElemTraits<T>;
   using v8 = typename Tr::v8;
@@ -291,6 +293,30 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     softmax_rest(R, s0, s1, pk, mx, force);
   };
 
+  // ABI v9 (seg_mass): the cumulative log-sum-exp through segment s of the rows this lane pair owns (log2 units; a number the
+  // running reference cancels out of) goes to seg_cum - or, for a K/V-range piece, to its slot of ws_cum.  Segment boundaries
+  // only: nothing here is on the per-tile path.
+  auto cum_store = [&](int rowoff, int s, float v2) {
+    const KArgs c = cold();
+    if (hi != 0) return;
+    if (npiece > 1) {
+      const int64_t prow = ((int64_t)((xcd * (c->sk_ix - c->sk_full) + (item_local - c->sk_full)) * npiece + piece)) * QB + wid * 64 + rowoff + lq;
+      c->ws_cum[prow * c->nseg_out + s] = v2;
+    } else if (qrowA + rowoff < c->Lq) {
+      c->seg_cum[(((int64_t)b * c->H + h) * c->Lq + qrowA + rowoff) * c->nseg_out + s] = v2 * 0.69314718f;
+    }
+  };
+  auto ref_log2 = [&](const RowBlock& R) { return QS ? R.m_run : R.m_run * c2; };
+  auto row_sum_now = [&](const RowBlock& R) {
+    const float ls = (R.la[0] + R.la[1]) + (R.lb[0] + R.lb[1]);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  };
+  auto cum_boundary = [&](int sc) {   // without the fold the row sums run over all segments: they ARE the cumulative sums
+    const float la_ = row_sum_now(A), lb_ = row_sum_now(Bk);
+    cum_store(0, sc, ref_log2(A) + __log2f(la_));
+    cum_store(32, sc, ref_log2(Bk) + __log2f(lb_));
+  };
   // FOLD: close segment `sc`; `has_next`: another (reference) segment follows in this piece
   auto seg_row_sum = [&](RowBlock& R) {
     float ls = (R.la[0] + R.la[1]) + (R.lb[0] + R.lb[1]);
@@ -304,6 +330,10 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   auto fold_boundary = [&](int sc, bool has_next) {
     const float lsA = seg_row_sum(A), lsB = seg_row_sum(Bk);
     const KArgs c = cold();
+    if (MASS) {
+      cum_store(0, sc, ref_log2(A) + __log2f(A.l_done));
+      cum_store(32, sc, ref_log2(Bk) + __log2f(Bk.l_done));
+    }
     const bool cur_ref = !(c->include_self && sc == 0);
     const int64_t ao_c = ((int64_t)(b * c->N + (cur_ref ? sc - c->include_self : 0)) * c->H + h) * 64 + 4 * hi;
     const int64_t ao_n = ((int64_t)(b * c->N + (has_next ? sc + 1 - c->include_self : 0)) * c->H + h) * 64 + 4 * hi;
@@ -532,6 +562,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
     pv_tile(smem + V_OFF + cur * TILE_BYTES, pkA, pkB);
     if (++ct0 == c_ntile) {
       if (FOLD) fold_boundary(cseg, t + 1 < NTILES);
+      else if (MASS) cum_boundary(cseg);
       const KArgs c = cold();
       ct0 = 0; ++cseg; c_ntile = c->tiles_ref; c_len = c->Lr;
     }
@@ -547,6 +578,12 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
 
   // ---- epilogue (per row block) ---------------------------------------------------------------------
   if (FOLD && ct0 != 0) fold_boundary(cseg, false);  // a piece that stops inside a segment closes what it has
+  constexpr bool want_cum = MASS;
+  if (!FOLD && want_cum && ct0 != 0) cum_boundary(cseg);
+  const int s_next = cseg + (ct0 != 0 ? 1 : 0);       // first segment whose cumulative value this piece has not stored yet
+  if (want_cum && npiece > 1)
+    for (int s = 0; s < seg_b; ++s) { cum_store(0, s, -INFINITY); cum_store(32, s, -INFINITY); }   // segments before this piece's range
+  float lpreA = -1.f, lpreB = -1.f, pzA = 0.f, pzB = 0.f;   // zero suffix: row sum before it (final frame), weight of one zero segment
   // Zero-filled references in closed form (ABI v8): the nzero * Lr keys of the suffix all score exactly 0.  With the running
   // reference m (exponent domain) a zero score weighs 2^(-m): the reference first moves up to 0 if it was below (exact max,
   // once per launch), then the row sum takes nzero * Lr * 2^(-m) and - with the AdaIN fold - the output takes that weight
@@ -555,7 +592,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   if (nref < p.N && piece == npiece - 1) {
     const KArgs c = cold();
     const float nz = (float)(c->N - nref), lr = (float)c->Lr;
-    auto zero_suffix = [&](RowBlock& R) -> float {   // returns the weight of ONE zero segment (Lr keys)
+    auto zero_suffix = [&](RowBlock& R, float& l_pre) -> float {   // returns the weight of ONE zero segment (Lr keys)
       if (!QS && R.m_run == -INFINITY) R.m_run = 0.f;          // no tile walked at all: the reference starts at the zero score
       const float e = QS ? -R.m_run : -R.m_run * c2;           // exponent of a zero score relative to the reference
       const float up = max3(e, 0.f, 0.f);
@@ -567,11 +604,14 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       if (FOLD) R.l_done *= alpha;
       R.m_run += QS ? up : up / c2;
       const float pz = fast_exp2(e - up) * lr;
+      if (FOLD) l_pre = R.l_done;
+      else if (want_cum) l_pre = row_sum_now(R);
       if (FOLD) R.l_done += pz * nz;
       else if (hi == 0) R.la[0] += pz * nz;                    // the two lanes of a row add their partial sums in finish()
       return pz;
     };
-    const float pzA = zero_suffix(A), pzB = zero_suffix(Bk);
+    pzA = zero_suffix(A, lpreA);
+    pzB = zero_suffix(Bk, lpreB);
     if (FOLD) {
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) {
@@ -592,7 +632,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       }
     }
   }
-  auto finish = [&](RowBlock& R, int qrow, int rowoff) {
+  auto finish = [&](RowBlock& R, int qrow, int rowoff, float l_pre, float pz) {
     float l_fin;
     if (FOLD) {
       l_fin = R.l_done;
@@ -600,6 +640,17 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
       float ls = (R.la[0] + R.la[1]) + (R.lb[0] + R.lb[1]);
       const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ls), __float_as_uint(ls), false, false);
       l_fin = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    if (want_cum) {
+      // segments after the end of this piece's range: the piece's total - and, on the piece that owns the zero-filled suffix,
+      // the row sum before the suffix plus j zero segments
+      const KArgs c = cold();
+      const float lp = l_pre < 0.f ? l_fin : l_pre, mref = ref_log2(R);
+      const int sz = c->include_self + nref;
+      for (int s = s_next; s < c->nseg_out; ++s) {
+        const int j = s - sz + 1;
+        cum_store(rowoff, s, mref + __log2f(lp + pz * (float)(j > 0 ? j : 0)));
+      }
     }
     const float m_raw = QS ? R.m_run / p.scale_log2 : R.m_run;   // the combine kernel and the LSE work in raw-score units
     if (npiece > 1) {
@@ -641,12 +692,13 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         p.lse[((int64_t)b * p.H + h) * p.Lq + qrow] = m_raw * p.scale + __logf(l_fin);
     }
   };
-  finish(A, qrowA, 0);
-  finish(Bk, qrowB, 32);
+  finish(A, qrowA, 0, lpreA, pzA);
+  finish(Bk, qrowB, 32, lpreB, pzB);
 }
 
-template <typename T, bool FOLD, int NW = 4, bool QS = false, int ABL = 0>
+template <typename T, bool FOLD, int NW = 4, bool QS = false, int ABL = 0, bool MASS = false>
 hipError_t launch(const AttnKParams& p0, hipStream_t s) {
+  if (!MASS && p0.seg_cum != nullptr) return hipErrorInvalidValue;   // seg_mass: the 8-wave forms carry the MASS instantiation
   AttnKParams p = p0;
   constexpr int QB = NW * 64;
   p.nqb = (p.Lq + QB - 1) / QB;
@@ -660,7 +712,7 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   int rem = p.sk_ix - full;
   int k = 1;
   if (p.ws != nullptr && rem > 0) {
-    const size_t piece_bytes = (size_t)QB * 66 * sizeof(float);
+    const size_t piece_bytes = (size_t)QB * (66 + (p.seg_cum != nullptr ? p.nseg_out : 0)) * sizeof(float);
     k = ir_pick_split(rem, slots_x, p.ntiles / 8 /* pieces of at least 8 tiles */, (long)(p.ws_bytes / piece_bytes / 8));
   }
   if (k <= 1) { full = p.sk_ix; rem = 0; k = 1; }
@@ -668,6 +720,7 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   p.sk_k = k;
   p.ws_o = p.ws;
   p.ws_ml = p.ws + (size_t)8 * rem * k * QB * 64;
+  p.ws_cum = p.ws_ml + (size_t)8 * rem * k * QB * 2;
   const int grid = 8 * (full + rem * k);
   size_t dyn_lds = 0;
   if (QS) {
@@ -676,13 +729,13 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
     if (!attr_set[dev]) {
-      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, QS, ABL>,
+      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, QS, ABL, MASS>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
       if (ea != hipSuccess) return ea;
       attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, QS, ABL>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
+  hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, QS, ABL, MASS>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || k <= 1) return e;
   return ir_launch_shared_attn_combine(p, std::is_same<T, __bf16>::value ? 1 : 0, QB, rem, s);
@@ -690,17 +743,17 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
 
 }  // namespace
 
+template <bool QS, bool MASS>
 static hipError_t launch_x8(const AttnKParams& p, int dtype, hipStream_t s) {
-  if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8>(p, s) : launch<_Float16, true, 8>(p, s);
-  return dtype == 1 ? launch<__bf16, false, 8>(p, s) : launch<_Float16, false, 8>(p, s);
+  if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8, QS, 0, MASS>(p, s) : launch<_Float16, true, 8, QS, 0, MASS>(p, s);
+  return dtype == 1 ? launch<__bf16, false, 8, QS, 0, MASS>(p, s) : launch<_Float16, false, 8, QS, 0, MASS>(p, s);
 }
 
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s) {  // 8-wave (512-row) workgroups
-  if (p.q_prescaled) {   // IR_FLAG_Q_PRESCALED: the QS instantiation
-    if (p.aa != nullptr) return dtype == 1 ? launch<__bf16, true, 8, true>(p, s) : launch<_Float16, true, 8, true>(p, s);
-    return dtype == 1 ? launch<__bf16, false, 8, true>(p, s) : launch<_Float16, false, 8, true>(p, s);
-  }
-  return launch_x8(p, dtype, s);
+  const bool mass = p.seg_cum != nullptr;
+  if (p.q_prescaled)   // IR_FLAG_Q_PRESCALED: the QS instantiation
+    return mass ? launch_x8<true, true>(p, dtype, s) : launch_x8<true, false>(p, dtype, s);
+  return mass ? launch_x8<false, true>(p, dtype, s) : launch_x8<false, false>(p, dtype, s);
 }
 
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s) {

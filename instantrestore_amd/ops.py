@@ -194,10 +194,13 @@ def _prep(q, k_self, v_self, ref_k, ref_v, heads, include_self, adain):
 def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, scale: float,
                      include_self: bool = True, adain: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
                      return_lse: bool = False, split: bool = True, q_prescaled: bool = False,
-                     out_dtype: Optional[torch.dtype] = None, valid_refs: Optional[torch.Tensor] = None):
+                     out_dtype: Optional[torch.dtype] = None, valid_refs: Optional[torch.Tensor] = None,
+                     return_mass: bool = False):
     """Fused extended self-attention (``ir_shared_attn_fwd``).
 
-    Returns ``out`` (B, Lq, H*64) in q's dtype [and ``lse`` (B, H, Lq) fp32].  ``adain`` is the
+    Returns ``out`` (B, Lq, H*64) in q's dtype [, ``lse`` (B, H, Lq) fp32] [, ``mass`` (B, H, Lq, include_self + N) fp32:
+    ``return_mass``, ABI v9 ``seg_mass`` - the attention mass of every K/V segment as a by-product of the same launch, what
+    gradio_demo.py:119-127 reduces ``attention_probs`` to].  ``adain`` is the
     (a, b) pair from :func:`adain_stats`; the reference-V renormalisation happens inside the
     kernel's V staging.  ``q_prescaled``: ``q`` already holds ``Q * scale * log2(e)`` (``IR_FLAG_Q_PRESCALED``: the
     fused q/k/v projection folds the factor into its weights; ``scale`` stays the reference's ``attn.scale``).
@@ -213,6 +216,11 @@ def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, s
     out = torch.empty((q.shape[0], q.shape[1], heads * HEAD_DIM), dtype=out_dtype or q.dtype, device=q.device)
     lse = torch.empty((q.shape[0], heads, q.shape[1]), dtype=torch.float32, device=q.device) if return_lse else None
     args = _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adain, out, lse, split, q_prescaled, valid_refs)
+    mass = None
+    if return_mass:
+        nseg = (1 if include_self else 0) + (ref_k.shape[1] if ref_k is not None else 0)
+        mass = torch.empty((q.shape[0], heads, q.shape[1], nseg), dtype=torch.float32, device=q.device)
+        args.seg_mass = mass.data_ptr()
     sink = EVENT_SINK
     if sink is not None and sink[0](q, ref_k, adain):   # bench.py: HIP events around chosen launches, in situ
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -222,7 +230,8 @@ def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads: int, s
         sink[1].append((e0, e1))
     else:
         _lib.check(_lib.lib().ir_shared_attn_fwd(C.byref(args), _stream()), "ir_shared_attn_fwd")
-    return (out, lse) if return_lse else out
+    res = (out,) + ((lse,) if return_lse else ()) + ((mass,) if return_mass else ())
+    return res if len(res) > 1 else out
 
 
 @_on_tensor_device

@@ -20,7 +20,7 @@ def _np(t):
 
 
 def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads, scale, include_self=True,
-                     adain=None, return_lse=False, valid_refs=None):
+                     adain=None, return_lse=False, valid_refs=None, return_mass=False):
     """``valid_refs``: the caller's promise that references n >= valid_refs[b] are all-zero; the oracle walks them like any
     other (that IS the semantics: zeroed, not masked) and the stand-in only checks the promise"""
     CALLS.append(("shared_attention", dict(include_self=include_self, adain=adain is not None,
@@ -35,14 +35,25 @@ def shared_attention(q, k_self, v_self, ref_k=None, ref_v=None, *, heads, scale,
         rvn = rvn * a + b
     out, probs = O.shared_attention_np(qn, kn, vn, rkn, rvn, heads, scale, False, include_self, return_probs=True)
     out = torch.from_numpy(out).to(q.dtype)
-    if not return_lse:
-        return out
-    qh = O.head_to_batch_dim_np(qn, heads)
-    ek, _ = O.extended_kv_np(kn, vn, rkn, rvn, heads, False, include_self)
-    s = np.matmul(qh, ek.transpose(0, 2, 1)) * scale
-    m = s.max(-1)
-    lse = (m + np.log(np.exp(s - m[..., None]).sum(-1))).reshape(q.shape[0], heads, q.shape[1])
-    return out, torch.from_numpy(lse).float()
+    res = (out,)
+    if return_lse:
+        qh = O.head_to_batch_dim_np(qn, heads)
+        ek, _ = O.extended_kv_np(kn, vn, rkn, rvn, heads, False, include_self)
+        s = np.matmul(qh, ek.transpose(0, 2, 1)) * scale
+        m = s.max(-1)
+        lse = (m + np.log(np.exp(s - m[..., None]).sum(-1))).reshape(q.shape[0], heads, q.shape[1])
+        res += (torch.from_numpy(lse).float(),)
+    if return_mass:   # ABI v9 seg_mass: the probabilities summed per K/V segment
+        res += (_segment_sums(probs, kn, rkn, include_self),)
+    return res if len(res) > 1 else out
+
+
+def _segment_sums(p, kn, rkn, include_self):
+    edges = [0] + ([kn.shape[1]] if include_self else [])
+    for n in range(0 if rkn is None else rkn.shape[1]):
+        edges.append(edges[-1] + rkn.shape[2])
+    mass = np.stack([p[..., a:b].sum(-1) for a, b in zip(edges[:-1], edges[1:])], axis=-1)
+    return torch.from_numpy(mass).float()
 
 
 def attn_probs(q, k_self, ref_k, lse, *, heads, scale, include_self=True, q_prescaled=False):
@@ -56,11 +67,7 @@ def attn_segment_mass(q, k_self, ref_k, lse, *, heads, scale, include_self=True,
     CALLS.append(("attn_segment_mass", {}))
     qn, kn, rkn = map(_np, (q, k_self, ref_k))
     _, p = O.shared_attention_np(qn, kn, kn, rkn, rkn, heads, scale, False, include_self, return_probs=True)
-    edges = [0] + ([kn.shape[1]] if include_self else [])
-    for n in range(0 if rkn is None else rkn.shape[1]):
-        edges.append(edges[-1] + rkn.shape[2])
-    mass = np.stack([p[..., a:b].sum(-1) for a, b in zip(edges[:-1], edges[1:])], axis=-1)
-    return torch.from_numpy(mass).float()
+    return _segment_sums(p, kn, rkn, include_self)
 
 
 def adain_stats(v_self, ref_v, *, heads, eps=ADAIN_EPS):

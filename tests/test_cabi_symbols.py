@@ -48,7 +48,7 @@ def test_struct_mirror_matches_header_field_order():
         else:
             fields.append(names.lstrip("*"))
     assert fields == [f[0] for f in _lib.SharedAttnArgs._fields_]
-    assert C.sizeof(_lib.SharedAttnArgs) == 10 * 4 + 9 * 8 + 20 * 8 + 16 + 8 + 8   # + valid_refs (ABI v8)
+    assert C.sizeof(_lib.SharedAttnArgs) == 10 * 4 + 9 * 8 + 20 * 8 + 16 + 8 + 8 + 8   # + valid_refs (ABI v8) + seg_mass (ABI v9)
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
@@ -101,6 +101,10 @@ def test_abi_v8_entry_points_validate_without_a_gpu():
     a.o_sb, a.o_sl, a.o_sh = 64 * 64, 64, 64
     a.valid_refs = C.cast(C.c_void_p(ptr.value + 2), C.c_void_p)                                # not 4-byte aligned
     assert lib.ir_shared_attn_fwd(C.byref(a), None) == -2 and b"valid_refs" in lib.ir_last_error_string()
+    a.valid_refs = None
+    a.seg_mass = C.cast(C.c_void_p(ptr.value + 2), C.c_void_p)                                  # ABI v9: not 4-byte aligned
+    assert lib.ir_shared_attn_fwd(C.byref(a), None) == -2 and b"seg_mass" in lib.ir_last_error_string()
+    a.seg_mass = None
     # tile picker: M = 2048 x N = 1280 x K = 1280 (160 tiles of 128 x 128 on 256 CUs) takes the split-K tile (id 9); the same
     # rows at N = 3840 (480 tiles) and the K = 640 shapes do not
     assert lib.ir_linear_kernel_for(2048, 1280, 1280, 1) == 9

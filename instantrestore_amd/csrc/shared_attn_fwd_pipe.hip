@@ -600,10 +600,13 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
-  if (FOLD && ct0 != 0) fold_segment();  // a piece that stops inside a segment folds what it has
+  // a piece that stops inside a segment folds what it has.  Not an EMPTY piece (valid_refs can leave an item fewer tiles than
+  // the split planned pieces for): nothing is accumulated, both references are still -inf and their difference is not a number
+  const bool mid = ct0 != 0 && NTILES > 0;
+  if (FOLD && mid) fold_segment();
   constexpr bool want_cum = MASS;
-  if (!FOLD && want_cum && ct0 != 0) cum_store(cseg, ref_log2() + __log2f(row_sum_now()));
-  const int s_next = cseg + (ct0 != 0 ? 1 : 0);   // first segment whose cumulative value this piece has not stored yet
+  if (!FOLD && want_cum && mid) cum_store(cseg, ref_log2() + __log2f(row_sum_now()));
+  const int s_next = cseg + (mid ? 1 : 0);        // first segment whose cumulative value this piece has not stored yet
   if (want_cum && npiece > 1)
     for (int s = 0; s < seg_b; ++s) cum_store(s, -INFINITY);   // segments before this piece's range
   float l_pre = -1.f, pz_seg = 0.f;               // zero suffix: row sum before it (final frame), weight of one zero segment
@@ -619,8 +622,13 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
     m_run += PRESC ? up : up / c2;
     const float pz = fast_exp2(e - up) * (float)p.Lr;          // weight of ONE zero segment (Lr keys); bs below sums the segments' shifts
     pz_seg = pz;
-    if (FOLD) l_pre = l_tot * alpha;
-    else if (want_cum) l_pre = row_sum_now() * alpha;
+    if (want_cum) {
+      // (through an opaque copy: sharing l_tot * alpha with the update below would change how THAT contracts into a
+      //  multiply-add, and with it the last bit of the result relative to the launch without the by-product)
+      float lt = FOLD ? l_tot : row_sum_now();
+      asm volatile("" : "+v"(lt));
+      l_pre = lt * alpha;
+    }
     if (FOLD) {
       l_tot = l_tot * alpha + pz * nz;
       m_ot = m_run;

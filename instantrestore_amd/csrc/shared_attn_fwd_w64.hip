@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
   }
 
   // ---- epilogue (per row block) ---------------------------------------------------------------------
-  if (FOLD && ct0 != 0) fold_boundary(cseg, false);  // a piece that stops inside a segment closes what it has
+  if (FOLD && ct0 != 0) fold_boundary(cseg, false);  // a piece that stops inside a segment closes what it has (an empty piece: zeros)
   constexpr bool want_cum = MASS;
   if (!FOLD && want_cum && ct0 != 0) cum_boundary(cseg);
   const int s_next = cseg + (ct0 != 0 ? 1 : 0);       // first segment whose cumulative value this piece has not stored yet

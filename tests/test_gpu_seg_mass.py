@@ -9,6 +9,8 @@ quantity on the way), against the second-pass kernel ``ir_attn_segment_mass`` (a
 order), rows summing to 1, the attention output BIT-identical to the launch without the by-product, with and without the AdaIN
 fold, the self segment, pre-scaled Q, ragged segment lengths, zero-filled references closed analytically (``valid_refs``) and the
 K/V-range pieces of the remainder split (the cfg-2 shapes of both kernels)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -166,27 +168,28 @@ SPLIT_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("presc", [True, False], ids=["prescq-bf16", "plainq-f16"])
 @pytest.mark.parametrize("t", [0, 1], ids=["noself", "self"])
 @pytest.mark.parametrize("adain", [False, True], ids=["noadain", "adain"])
 @pytest.mark.parametrize("shape", SPLIT_SHAPES, ids=["L1024", "L4096"])
-def test_mass_through_the_remainder_split_at_the_cfg2_shapes(ops, shape, adain, t):
+def test_mass_through_the_remainder_split_at_the_cfg2_shapes(ops, shape, adain, t, presc):
     """At cfg 2 both kernels cut the items of their last, partially filled round into K/V-range pieces whose partial results a
     second kernel merges; a piece knows the cumulative sums of ITS key range only, the merge adds them up.  Compared with the
-    second-pass kernel (itself oracle-checked, tests/test_gpu_probs.py) at the real shape, pre-scaled Q as the processors launch
-    it, with every count of valid references in the batch."""
+    second-pass kernel (itself oracle-checked, tests/test_gpu_probs.py) at the real shape, pre-scaled Q in bf16 as the processors launch
+    it and plain Q in fp16, with every count of valid references in the batch."""
     _, B, H, L, N = shape
     C = H * 64
-    dtype = torch.bfloat16
+    dtype = torch.bfloat16 if presc else torch.float16
     torch.manual_seed(5)
-    q = (torch.randn(B, L, C, device="cuda") * 1.2 * QC).to(dtype)
+    q = (torch.randn(B, L, C, device="cuda") * 1.2 * (QC if presc else 1.0)).to(dtype)
     k, v = (torch.randn(B, L, C, device="cuda") * 1.2).to(dtype), torch.randn(B, L, C, device="cuda").to(dtype)
     rk, rv = (torch.randn(B, N, L, C, device="cuda") * 1.2).to(dtype), torch.randn(B, N, L, C, device="cuda").to(dtype)
     aff = ops.adain_stats(v, rv, heads=H) if adain else None
-    kw = dict(heads=H, scale=0.125, include_self=bool(t), adain=aff, q_prescaled=True)
+    kw = dict(heads=H, scale=0.125, include_self=bool(t), adain=aff, q_prescaled=presc)
     out0, lse = ops.shared_attention(q, k, v, rk, rv, return_lse=True, **kw)
     out, mass = ops.shared_attention(q, k, v, rk, rv, return_mass=True, **kw)
     nosplit = ops.shared_attention(q, k, v, rk, rv, return_mass=True, split=False, **kw)[1]
-    second = ops.attn_segment_mass(q, k, rk, lse, heads=H, scale=0.125, include_self=bool(t), q_prescaled=True)
+    second = ops.attn_segment_mass(q, k, rk, lse, heads=H, scale=0.125, include_self=bool(t), q_prescaled=presc)
     assert torch.equal(out, out0)
     assert float((mass - second).abs().max()) <= 1e-4, float((mass - second).abs().max())
     assert float((nosplit - second).abs().max()) <= 1e-4
@@ -202,7 +205,9 @@ def test_mass_through_the_remainder_split_at_the_cfg2_shapes(ops, shape, adain, 
     kw["adain"] = aff
     walked = ops.shared_attention(q, k, v, rk, rv, return_mass=True, **kw)[1]
     closed = ops.shared_attention(q, k, v, rk, rv, return_mass=True, valid_refs=valid, **kw)[1]
-    assert float((walked - closed).abs().max()) <= 2e-5, float((walked - closed).abs().max())
+    # (the walk adds up to 16 384 equal terms per zero segment one by one in fp32 - the closed form is the exact product: the plain-Q
+    #  kernels, which add every probability straight into the running sums, come out up to 4e-5 apart, the pre-scaled ones 1e-5)
+    assert float((walked - closed).abs().max()) <= 1e-4, float((walked - closed).abs().max())
     assert float((closed.sum(-1) - 1).abs().max()) <= 1e-5
 
 
@@ -221,16 +226,19 @@ def test_kernels_without_the_by_product_refuse_it(ops):
 
 
 def test_seeded_sweep_of_by_product_masses(ops):
-    """random small shapes, both kernels' default forms, every flag combination: by-product vs second pass"""
-    rng = np.random.default_rng(2029)
-    gen = torch.Generator().manual_seed(2029)
-    for case in range(60):
+    """random small shapes, both kernels' default forms, every flag combination: by-product vs second pass
+    (IR_SWEEP_CASES / IR_SWEEP_SEED / IR_SWEEP_MAXLQ / IR_SWEEP_MAXLR widen it for a soak)"""
+    seed = int(os.environ.get("IR_SWEEP_SEED", "2029"))
+    max_lq, max_lr = int(os.environ.get("IR_SWEEP_MAXLQ", "400")), int(os.environ.get("IR_SWEEP_MAXLR", "300"))
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator().manual_seed(seed)
+    for case in range(int(os.environ.get("IR_SWEEP_CASES", "60"))):
         B, H = int(rng.integers(1, 3)), int(rng.integers(1, 4))
-        Lq = int(rng.integers(1, 400))
+        Lq = int(rng.integers(1, max_lq))
         N = int(rng.integers(0, 6))
-        Lr = int(rng.integers(8, 300)) if N else 0
+        Lr = int(rng.integers(8, max_lr)) if N else 0
         inc = bool(rng.integers(0, 2)) or N == 0
-        Ls = Lq if rng.integers(0, 2) else int(rng.integers(1, 300))
+        Ls = Lq if rng.integers(0, 2) else int(rng.integers(1, max_lr))
         adain = bool(N and rng.integers(0, 2))
         presc = bool(rng.integers(0, 2))
         dtype = [torch.float16, torch.bfloat16][case % 2]

@@ -62,6 +62,12 @@ SMALL = [
     (2, 1, 1024, 4, 1024, True, [3, 1]),         # 32x32-token class
     (2, 3, 200, 5, 72, True, [2, 5]),            # ragged tiles, partial query block
     (9, 2, 1024, 4, 1024, True, [4, 3, 2, 1, 0, 1, 2, 3, 4]),   # remainder split of the item grid with per-item K/V ranges
+    # a short self segment before long references, none of them valid: the split plans its pieces from the FULL tile count (2 + 5 * 6),
+    # the item has two tiles - some pieces are EMPTY, and one of them "stops inside" the self segment.  (Found by the widened
+    # sweep of tests/test_gpu_seg_mass.py: the 32-row kernel's fold of such a piece took 2^(-inf - -inf) and returned NaN rows.)
+    (1, 2, 97, 5, 373, True, [0]),
+    (2, 2, 128, 5, 373, True, [0, 1]),
+    (2, 1, 70, 5, 373, False, [0, 1]),
 ]
 
 

@@ -196,8 +196,7 @@ def test_mass_through_the_remainder_split_at_the_cfg2_shapes(ops, shape, adain, 
     assert float((mass.sum(-1) - 1).abs().max()) <= 1e-5
     # ragged valid counts: zero the suffixes, pass the counts, compare with the walk over the zero tiles
     valid = torch.tensor([(b % (N + 1)) for b in range(B)], dtype=torch.int32, device="cuda")
-    if not t:
-        valid.clamp_(min=1)
+    # (entry 0 and entry N + 1 have NO valid reference: without the self segment every key of theirs is zero, the item owns no tile at all)
     for b in range(B):
         rk[b, int(valid[b]):] = 0
         rv[b, int(valid[b]):] = 0

@@ -218,6 +218,7 @@ def test_golden_shared_processor(ops, golden, m):
                                save_self_attentions=m["save_probs"], use_adain=m["use_adain"],
                                train_input=m["train_input"])
     attn.set_processor(proc)
+    proc.save_attention_mass = bool(m["save_probs"])    # round 5 (ABI v9): the masses as a by-product of the same launch, checked below
     with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
         out = attn(hidden, encoder_hidden_states=enc, **kwargs)
     assert out.shape == hidden.shape and out.dtype == dtype
@@ -268,6 +269,12 @@ def test_golden_shared_processor(ops, golden, m):
         mass = lambda a: a.reshape(*a.shape[:-1], nblk, w).sum(-1)
         assert np.abs(mass(pn) - mass(p2)).max() <= 4 * TOL[dtype]
         assert np.abs(mass(pn) - mass(p_ref)).max() <= (8 if m["peaky"] else 4) * TOL[dtype]
+        # ... and the masses the attention launch itself left behind (no tensor, no second pass) against the REFERENCE's dump
+        am = proc.attention_mass.cpu().numpy()
+        assert am.shape == mass(p_ref).shape and proc.attention_mass.dtype == torch.float32
+        assert np.abs(am - mass(p2)).max() <= 4 * TOL[dtype]
+        assert np.abs(am - mass(p_ref)).max() <= (8 if m["peaky"] else 4) * TOL[dtype]
+        assert np.abs(am.sum(-1) - 1).max() <= 1e-5
     assert len(proc.state_dict()) == 0
 
 

@@ -225,3 +225,69 @@ def test_fp32_activations_are_cast_while_loaded(dtype, shape):
     a = ops.linear(x, w, bias)
     b = ops.linear(x.to(dtype), w, bias)
     assert a.dtype == dtype and torch.equal(a, b)
+
+
+def test_randomised_projection_shapes_every_kernel():
+    """seeded sweep (IR_SWEEP_CASES / IR_SWEEP_SEED widen it): random M (whole tiles, ragged tails, one row), N, K over both kernel
+    families, bias or not, 16-bit or fp32 activations, rows of X with a pitch larger than K, a scaled leading column range - through
+    the automatic choice AND through every kernel that accepts the shape, against a float64 product of the same rounded operands;
+    the statistics-tail form must return the same bits of Y where a shape can carry it"""
+    import os
+    from instantrestore_amd import ops
+    seed = int(os.environ.get("IR_SWEEP_SEED", "404"))
+    rng = np.random.default_rng(seed)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    ks = [32, 64, 96, 128, 160, 192, 256, 288, 320, 384, 512, 640, 704, 768, 1024, 1280, 1344]
+    tried = {}
+    for case in range(int(os.environ.get("IR_SWEEP_CASES", "40"))):
+        dtype = [torch.bfloat16, torch.float16][case % 2]
+        K = int(rng.choice(ks))
+        N = 32 * int(rng.integers(1, 41)) if rng.integers(0, 3) else 64 * int(rng.integers(1, 61))
+        mode = int(rng.integers(0, 4))
+        M = [int(rng.integers(1, 70)), int(rng.integers(1, 3000)), 64 * int(rng.integers(1, 80)), 256 * int(rng.integers(1, 40)) + int(rng.integers(0, 2))][mode]
+        bias = bool(rng.integers(0, 2))
+        f32 = bool(rng.integers(0, 2))
+        pitch = K + 8 * int(rng.integers(0, 4))
+        xbuf = torch.randn(M, pitch, device="cuda", generator=g)
+        x32 = xbuf[:, :K]
+        x16 = x32.to(dtype)
+        x = x32 if f32 else (torch.empty(M, pitch, dtype=dtype, device="cuda")[:, :K].copy_(x16))
+        w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(dtype)
+        b = torch.randn(N, device="cuda", generator=g).to(dtype) if bias else None
+        sc = 32 * int(rng.integers(0, N // 32 + 1)) if rng.integers(0, 2) else 0
+        what = f"case {case}: M{M} N{N} K{K} bias{bias} f32{f32} pitch{pitch} scale_cols{sc} {dtype}"
+        if not ops.linear_supported(x, w, b):
+            continue
+        acc = x16.double() @ w.double().T
+        if sc:
+            acc[:, :sc] = acc[:, :sc] * float(np.float32(0.18))     # the fp32 accumulator times the fp32 factor, before bias and rounding
+        ref = acc + (b.double() if bias else 0.0)
+        bound = TOL[dtype] * torch.clamp(ref.abs(), min=1.0)
+        auto = None
+        for name, kid in ops.LIN_KERNELS.items():
+            try:
+                y = ops.linear(x, w, b, kernel=kid, scale_cols=sc, col_scale=0.18)
+            except RuntimeError:
+                assert kid != 0, what                      # the automatic choice must serve what linear_supported accepted
+                continue
+            tried[name] = tried.get(name, 0) + 1
+            assert y.shape == (M, N) and y.dtype == dtype, (what, name)
+            err = (y.double() - ref).abs()
+            assert bool((err <= bound).all()), (what, name, float((err - bound).max()))
+            if kid == 0:
+                auto = y
+        rows = ops.linear_stats_rows(M, N, K, bias)
+        if rows > 0 and N >= 64:
+            heads = N // 64
+            h0 = int(rng.integers(0, heads))
+            hc = int(rng.integers(1, heads - h0 + 1))
+            ys, st = ops.linear(x, w, b, scale_cols=sc, col_scale=0.18, stats=(64 * h0, 64 * hc))
+            assert torch.equal(ys, auto), what
+            # the partials of the column range merge into the token mean of those columns (one set of M rows)
+            if M // rows <= ops.STATS_MAX_CHUNKS:
+                mean, std = ops.token_stats_from_partials(st, 1, M)
+                cols = ys[:, 64 * h0:64 * (h0 + hc)].double()
+                assert float((mean.reshape(-1).double() - cols.mean(0)).abs().max()) <= 1e-3 * max(1.0, float(cols.abs().max())), what
+                if M > 1:
+                    assert float((std.reshape(-1).double() - cols.std(0)).abs().max()) <= 2e-3 * max(1.0, float(cols.abs().max())), what
+    print("linear sweep: launches per kernel", tried)

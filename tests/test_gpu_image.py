@@ -154,3 +154,46 @@ def test_sharded_image_path_on_one_rank_equals_the_unfused_bytes():
     packed = LanczosPreprocessor(S, torch.float16)([im for ident in images for im in ident]).view(total, 1 + n_refs, 3, S, S)
     want = ops.tensor2im_u8(step(packed[:, 0], packed[:, 1:]))
     assert got.dtype == torch.uint8 and tuple(got.shape) == (total, S, S, 3) and torch.equal(got, want)
+
+
+def test_randomised_source_sizes_equal_the_oracle():
+    """seeded sweep (IR_SWEEP_CASES / IR_SWEEP_SEED widen it): sources from 17 to 1700 pixels a side - far smaller and far larger than
+    the target, extreme aspect ratios, odd sizes, padded rows - and targets of 64 ... 512 pixels, one launch per target size over a
+    ragged batch: the device bytes must be the oracle's (Pillow's fixed-point Lanczos, resize-shorter-side + centre crop +
+    normalise; inference/test.py:54-59) everywhere"""
+    from instantrestore_amd.preprocess import LanczosPreprocessor
+    seed = int(os.environ.get("IR_SWEEP_SEED", "17"))
+    rng = np.random.default_rng(seed)
+    cases = int(os.environ.get("IR_SWEEP_CASES", "24"))
+    done = 0
+    while done < cases:
+        size = int(rng.choice([64, 96, 128, 256, 512]))
+        n = int(rng.integers(1, 7))
+        imgs, dev = [], []
+        for i in range(n):
+            kind = int(rng.integers(0, 4))
+            if kind == 0:      # smaller than the target (up-sampling), down to a sliver
+                h, w = int(rng.integers(17, size + 1)), int(rng.integers(17, size + 1))
+            elif kind == 1:    # extreme aspect ratio
+                h, w = int(rng.integers(17, 200)), int(rng.integers(600, 1700))
+                if rng.integers(0, 2):
+                    h, w = w, h
+            else:
+                h, w = int(rng.integers(size // 2, 1700)), int(rng.integers(size // 2, 1700))
+            a = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            if rng.integers(0, 2):   # smooth content in one channel: long runs of equal taps products, saturation at both ends
+                yy, xx = np.mgrid[0:h, 0:w]
+                a[..., i % 3] = ((np.sin(yy / 5.0) * np.cos(xx / 9.0)) * 140 + 128).clip(0, 255).astype(np.uint8)
+            imgs.append(a)
+            if rng.integers(0, 3) == 0:   # rows padded: src_row_bytes != 3 * in_w
+                pad = int(rng.integers(1, 9))
+                buf = torch.zeros((h, w + pad, 3), dtype=torch.uint8, device="cuda")
+                buf[:, :w] = torch.from_numpy(a).cuda()
+                dev.append(buf[:, :w])
+            else:
+                dev.append(torch.from_numpy(a).cuda())
+        out = LanczosPreprocessor(size, torch.float32)(dev).cpu().numpy()
+        for i, a in enumerate(imgs):
+            want, _ = IO.preprocess_np(a, size)
+            assert np.array_equal(out[i], want), (seed, done, i, a.shape, size)
+        done += n

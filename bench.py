@@ -50,6 +50,8 @@ CONFIGS = {
     "cfg2": (8, 4, 512, "bf16", True),    # BASELINE.json configs[1]: the configuration the metric is quoted on
     "cfg4": (8, 8, 512, "bf16", True),    # 8 references
     "cfg5": (16, 4, 1024, "f16", True),   # 1024 px
+    "cfg1gpu": (1, 4, 512, "f16", True),  # configs[0]'s shape on the GPU: ONE identity under fp16 autocast, the way inference/test.py:79-111
+                                          # drives the model - launch-bound: what the host side costs per layer shows here
 }
 DT = {"bf16": torch.bfloat16, "f16": torch.float16}
 

@@ -266,6 +266,21 @@ def _same_16bit(q: torch.Tensor, *others: Optional[torch.Tensor]) -> List[Option
 # ------------------------------------------------------------------------------------------
 # K/V-capturing processor of the frozen reference UNet (attn_processors.py:22-97)
 # ------------------------------------------------------------------------------------------
+def _plain_setattr(self, name, value):
+    """``nn.Module.__setattr__`` for modules that own no parameter, buffer or submodule (these processors: strict
+    ``load_state_dict`` with an empty state, inference/test.py:47-50): plain attributes - the K/V stash, flags, events, streams -
+    skip the registry walk (2 us each, ~170 per eager one-identity step: tools/gpu_host_overhead.py); anything that IS a
+    parameter / module, or a name a registry already holds, takes the normal path."""
+    if (type(value) in _PLAIN_VALUE_TYPES or not isinstance(value, (nn.Parameter, nn.Module))) and \
+            name not in self._parameters and name not in self._buffers and name not in self._modules:
+        object.__setattr__(self, name, value)
+    else:
+        nn.Module.__setattr__(self, name, value)
+
+
+_PLAIN_VALUE_TYPES = frozenset((type(None), bool, int, float, str, list, tuple, dict, torch.Tensor))   # exact types: no registry business
+
+
 class ReferenceCaptureComplete(Exception):
     """raised by the LAST K/V-capturing processor when early exit is armed (``kv_harvest``): every
     ``keys`` / ``values`` the main UNet will read is stashed, the rest of the reference UNet's forward
@@ -275,6 +290,8 @@ class ReferenceCaptureComplete(Exception):
 class AttnProcessor(nn.Module):
     r"""Plain attention that stashes the PRE-head-split ``key`` / ``value`` projections
     ``(B*N, L, C)`` for later sharing (attn_processors.py:73-74)."""
+
+    __setattr__ = _plain_setattr
 
     def __init__(self):
         super().__init__()
@@ -383,6 +400,8 @@ class SharedAttnProcessor(nn.Module):
     ``exp(0)`` weight, and with ``use_adain`` every reference V is renormalised to the
     statistics of this image's own V inside the kernel's V staging.
     """
+
+    __setattr__ = _plain_setattr
 
     def __init__(self, self_attn_idx: int = None, save_self_attentions: bool = False,
                  use_adain: bool = False, train_input: bool = True):

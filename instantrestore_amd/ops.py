@@ -40,7 +40,15 @@ def _dtype_code(t: torch.Tensor) -> int:
         ) from None
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)   # the handle without a torch.cuda.Stream object around it
+
+
 def _stream() -> int:
+    """the calling thread's current HIP stream on the current device, as the integer the C ABI takes.  Through torch's raw
+    accessor where this torch has it (what its own compiled kernels use): ``torch.cuda.current_stream()`` builds a Stream object
+    per call, ~7 us of the ~30 us a launch costs the host - a fifth of an eager one-identity step (tools/gpu_host_overhead.py)"""
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -144,7 +152,8 @@ _WS = {}
 
 def _workspace(device: torch.device) -> torch.Tensor:
     """one scratch buffer per (device, stream): launches on one stream are ordered, so reuse is safe"""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _RAW_STREAM(device.index) if _RAW_STREAM is not None and device.index is not None
+           else torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(_lib.lib().ir_shared_attn_workspace_bytes() // 4, dtype=torch.float32, device=device)
@@ -452,7 +461,16 @@ def linear_supported(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
             and (bias is None or (bias.dtype == weight.dtype and bias.is_contiguous()))):
         return False
     rows = x.numel() // k
-    return _lib.lib().ir_linear_kernel_for(rows, n, k, 0 if bias is None else 1) >= 0
+    key = (rows, n, k, bias is None)
+    ok = _KERNEL_FOR.get(key)
+    if ok is None:      # a pure function of the shape: asked once per shape, not once per launch
+        if len(_KERNEL_FOR) > 4096:
+            _KERNEL_FOR.clear()
+        ok = _KERNEL_FOR[key] = _lib.lib().ir_linear_kernel_for(rows, n, k, 0 if bias is None else 1) >= 0
+    return ok
+
+
+_KERNEL_FOR = {}
 
 
 def linear_kernel_for(rows: int, n: int, k: int, bias: bool) -> int:

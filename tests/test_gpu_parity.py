@@ -497,6 +497,85 @@ def test_randomised_shape_sweep(ops):
         _check(out, ref, dtype, f"sweep case {case}: B{B} H{H} Lq{Lq} N{N} Lr{Lr} inc{inc} ad{ad}")
 
 
+def test_randomised_modes_every_product_kernel(ops):
+    """seeded sweep over the MODES of ``ir_shared_attn_fwd`` (IR_SWEEP_CASES / IR_SWEEP_SEED / IR_SWEEP_MAXLQ / IR_SWEEP_MAXLR widen it):
+    every product kernel the mode admits (default dispatch and each tuning), plain or pre-scaled Q, q / k / v as the strided
+    thirds of one fused (B, L, 3C) projection output, reference K / V with padded token and batch pitches, a self K/V of another
+    length than the query axis, the remainder split on or off, fp32 output (the pre-rounding result), zero-filled references
+    with and without the counts, the LSE - against the float64 oracle on the same rounded operands"""
+    seed = int(os.environ.get("IR_SWEEP_SEED", "606"))
+    max_lq, max_lr = int(os.environ.get("IR_SWEEP_MAXLQ", "300")), int(os.environ.get("IR_SWEEP_MAXLR", "200"))
+    rng = np.random.default_rng(seed)
+    gen = torch.Generator().manual_seed(seed)
+    QC = 0.125 * 1.4426950408889634
+    used = {}
+    for case in range(int(os.environ.get("IR_SWEEP_CASES", "48"))):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        Lq = int(rng.integers(1, max_lq))
+        N = int(rng.integers(0, 7))
+        Lr = int(rng.integers(8, max_lr)) if N else 0
+        inc = bool(rng.integers(0, 2)) or N == 0
+        fused = bool(rng.integers(0, 2))                       # q / k / v are views of one (B, L, 3C) buffer: Ls == Lq
+        Ls = Lq if fused or rng.integers(0, 2) else int(rng.integers(1, max_lr))
+        ad = bool(rng.integers(0, 2)) and N > 0 and Ls > 1
+        presc = bool(rng.integers(0, 2))
+        dtype = [torch.float16, torch.bfloat16][case % 2]
+        variant = int(rng.choice([0, 0, 11, 13, 18] if presc else [0, 0, 7, 10, 12, 13, 14]))
+        split = bool(rng.integers(0, 4))
+        f32out = bool(rng.integers(0, 3) == 0)
+        C = H * 64
+        q, k, v = _rand((B, Lq, C), dtype, gen, 1.3), _rand((B, Ls, C), dtype, gen, 1.3), _rand((B, Ls, C), dtype, gen, 1.0, 0.2)
+        if presc:
+            q = (q.float() * QC).to(dtype)
+        rk = _rand((B, N, Lr, C), dtype, gen, 1.3) if N else None
+        rv = _rand((B, N, Lr, C), dtype, gen, 0.9, 0.4) if N else None
+        valid = None
+        if N and rng.integers(0, 2):
+            valid = [int(x) for x in rng.integers(0 if inc else 1, N + 1, B)]
+            for b in range(B):
+                rk[b, valid[b]:] = 0
+                rv[b, valid[b]:] = 0
+        pass_valid = valid is not None and bool(rng.integers(0, 2))
+        what = (f"modes case {case}: B{B} H{H} Lq{Lq} Ls{Ls} N{N} Lr{Lr} inc{inc} ad{ad} presc{presc} variant{variant} split{split} f32out{f32out} "
+                f"fused{fused} valid{valid} pass{pass_valid} {dtype}")
+        ref, p_ref = O.shared_attention_np(_np64(q), _np64(k), _np64(v), _np64(rk), _np64(rv), H, 0.6931471805599453 if presc else 0.125,
+                                           ad, inc, return_probs=True)
+        # device layouts
+        if fused:
+            buf = torch.empty(B, Lq, 3 * C, dtype=dtype, device="cuda")
+            buf[..., :C], buf[..., C:2 * C], buf[..., 2 * C:] = q.cuda(), k.cuda(), v.cuda()
+            qd, kd, vd = buf[..., :C], buf[..., C:2 * C], buf[..., 2 * C:]
+        else:
+            qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+        rkd = rvd = None
+        if N:
+            padl, padb = 8 * int(rng.integers(0, 3)), int(rng.integers(0, 2))
+            big_k = torch.zeros(B + padb, N, Lr, C + padl, dtype=dtype, device="cuda")
+            big_v = torch.zeros(B + padb, N, Lr, C + padl, dtype=dtype, device="cuda")
+            big_k[:B, ..., :C], big_v[:B, ..., :C] = rk.cuda(), rv.cuda()
+            rkd, rvd = big_k[:B, ..., :C], big_v[:B, ..., :C]
+        aff = ops.adain_stats(vd, rvd, heads=H) if ad else None
+        vt = torch.tensor(valid, dtype=torch.int32, device="cuda") if pass_valid else None
+        ops.set_attn_variant(variant)
+        try:
+            name = ops.shared_attention_kernel_name(qd, kd, vd, rkd, rvd, heads=H, scale=0.125, include_self=inc, adain=aff, q_prescaled=presc)
+            out, lse = ops.shared_attention(qd, kd, vd, rkd, rvd, heads=H, scale=0.125, include_self=inc, adain=aff, return_lse=True,
+                                            split=split, q_prescaled=presc, valid_refs=vt, out_dtype=torch.float32 if f32out else None)
+        finally:
+            ops.set_attn_variant(0)
+        used[name.split("<")[0] + f"/{variant}"] = used.get(name.split("<")[0] + f"/{variant}", 0) + 1
+        assert out.dtype == (torch.float32 if f32out else dtype), what
+        _check(out, ref, dtype, what)
+        # LSE (natural log of the row sums of exp(scale * scores)); with pre-scaled Q the scores are exponents: scale = ln 2
+        qh = O.head_to_batch_dim_np(_np64(q), H)
+        ek, _ = O.extended_kv_np(_np64(k), _np64(v), _np64(rk), _np64(rv), H, False, inc)
+        sc = np.matmul(qh, ek.transpose(0, 2, 1)) * (0.6931471805599453 if presc else 0.125)
+        mx = sc.max(-1)
+        lse_ref = (mx + np.log(np.exp(sc - mx[..., None]).sum(-1))).reshape(B, H, Lq)
+        assert np.abs(lse.cpu().numpy() - lse_ref).max() <= 2e-3 * max(1.0, np.abs(lse_ref).max()), what
+    print("modes sweep: kernels used", used)
+
+
 def test_hip_graph_capture_and_replay(ops):
     """the library allocates nothing and never synchronises: a whole processor call (projections,
     AdaIN statistics, fused attention with remainder split, out projection) can be captured in a

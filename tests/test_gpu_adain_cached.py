@@ -98,3 +98,52 @@ def test_shared_processor_output_is_unchanged_by_ref_stats(two_streams=False):
         bench._AUTOCAST["dtype"] = saved
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+def test_randomised_statistics_shapes_against_float64():
+    """seeded sweep (IR_SWEEP_CASES / IR_SWEEP_SEED widen it) over the standalone statistics kernels: token axes from 2 tokens to
+    several 256-row chunks and ragged ends, different lengths for style and content, channel means far from zero, strided views,
+    a zero-filled reference now and then.  ``ir_token_stats`` against float64 mean / unbiased std (1e-5 relative to the largest
+    entry), ``ir_adain_stats`` against the oracle's affine applied to the content (the reference's ``adain`` on float64,
+    attn_processors.py:7-18: 2e-4 relative), the cached form bit-identical to it, ``ir_adain_apply`` against x * a + b."""
+    import os
+    import numpy as np
+    from instantrestore_amd import ops
+    from oracle import shared_attn_oracle as O
+    seed = int(os.environ.get("IR_SWEEP_SEED", "808"))
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    for case in range(int(os.environ.get("IR_SWEEP_CASES", "40"))):
+        dtype = [torch.bfloat16, torch.float16][case % 2]
+        B, N, H = int(rng.integers(1, 4)), int(rng.integers(1, 6)), int(rng.integers(1, 5))
+        pick = lambda: int(rng.choice([rng.integers(8, 64), rng.integers(64, 600), 256 * rng.integers(1, 5) + rng.integers(-1, 2), rng.integers(600, 3000)]))
+        Ls, Lr = pick(), pick()
+        C = H * 64
+        shift_v, shift_x = float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))
+        sv, sx = float(rng.uniform(0.2, 2.0)), float(rng.uniform(0.2, 2.0))
+        v = (torch.randn(B, Ls, C, generator=g) * sv + shift_v).to(dtype)
+        rv = (torch.randn(B, N, Lr, C, generator=g) * sx + shift_x).to(dtype)
+        if rng.integers(0, 4) == 0:
+            rv[int(rng.integers(0, B)), int(rng.integers(0, N))] = 0          # zero-filled reference: (a, b) -> (~0, mean(V_self))
+        what = f"stats case {case}: B{B} N{N} H{H} Ls{Ls} Lr{Lr} shifts {shift_v:.2f}/{shift_x:.2f} {dtype}"
+        if rng.integers(0, 2):    # strided views (the V third of a fused projection output)
+            bv = torch.zeros(B, Ls, 3 * C, dtype=dtype, device="cuda"); bv[..., 2 * C:] = v.cuda(); vd = bv[..., 2 * C:]
+            br = torch.zeros(B, N, Lr, 3 * C, dtype=dtype, device="cuda"); br[..., 2 * C:] = rv.cuda(); rvd = br[..., 2 * C:]
+        else:
+            vd, rvd = v.cuda(), rv.cuda()
+        v64, rv64 = v.double().numpy(), rv.double().numpy()
+        m, sd = ops.token_stats(rvd, heads=H)
+        m_ref, sd_ref = rv64.mean(2), rv64.std(2, ddof=1)
+        assert np.abs(m.cpu().numpy().reshape(B, N, C) - m_ref).max() <= 1e-5 * max(1.0, np.abs(m_ref).max()), what
+        assert np.abs(sd.cpu().numpy().reshape(B, N, C) - sd_ref).max() <= 1e-5 * max(1.0, np.abs(sd_ref).max()) + 2e-6 * abs(shift_x), what
+        a, b = ops.adain_stats(vd, rvd, heads=H)
+        a1, b1 = ops.adain_stats_cached(vd, m, sd, heads=H)
+        assert torch.equal(a, a1) and torch.equal(b, b1), what
+        a_ref, b_ref = O.adain_affine_np(v64, rv64, H)
+        y_ref = rv64 * a_ref[:, :, None, :] + b_ref[:, :, None, :]
+        an, bn = a.cpu().numpy().astype(np.float64).reshape(B, N, 1, C), b.cpu().numpy().astype(np.float64).reshape(B, N, 1, C)
+        y_fp = rv64 * an + bn                                                   # the device's affine on the same content
+        assert np.abs(y_fp - y_ref).max() <= 2e-4 * max(1.0, np.abs(y_ref).max()), (what, np.abs(y_fp - y_ref).max())
+        y = ops.adain_apply(rvd, a, b, heads=H)
+        tol = (2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7) * max(1.0, np.abs(y_ref).max())
+        assert np.abs(y.double().cpu().numpy() - y_fp).max() <= tol, what

@@ -197,3 +197,27 @@ def test_randomised_source_sizes_equal_the_oracle():
             want, _ = IO.preprocess_np(a, size)
             assert np.array_equal(out[i], want), (seed, done, i, a.shape, size)
         done += n
+
+
+def test_randomised_freeu_filter_shapes():
+    """seeded sweep (IR_SWEEP_CASES / IR_SWEEP_SEED widen it): random plane counts and plane sizes up to the kernel's 4096 elements
+    (odd, non-square, 2 x 2), every admissible threshold, both signs of the scale - against the float64 FFT sequence
+    (block.py:3495-3520's fourier_filter) at the tolerance of test_freeu_fourier_filter"""
+    from instantrestore_amd import freeu
+    seed = int(os.environ.get("IR_SWEEP_SEED", "31"))
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    for case in range(int(os.environ.get("IR_SWEEP_CASES", "40"))):
+        dtype = [torch.float32, torch.float16, torch.bfloat16][case % 3]
+        H = int(rng.integers(2, 65))
+        W = int(rng.integers(2, min(64, 4096 // H) + 1))
+        B, C = int(rng.integers(1, 4)), int(rng.integers(1, 40))
+        thr = int(rng.integers(1, min(H, W) // 2 + 1))
+        scale = float(rng.uniform(-1.5, 2.0))
+        x = (torch.randn(B, C, H, W) * float(rng.uniform(0.2, 3.0)) + float(rng.uniform(-1, 1))).to(dtype)
+        ref = IO.fourier_filter_np(x.float().numpy(), thr, scale)
+        y = freeu.fourier_filter(x.cuda(), thr, scale)
+        err = np.abs(y.float().cpu().numpy().astype(np.float64) - ref).max()
+        amax = max(1.0, np.abs(ref).max(), float(x.float().abs().max()))
+        tol = {torch.float32: 4e-6, torch.float16: 2.0 ** -11 + 4e-6, torch.bfloat16: 2.0 ** -8 + 4e-6}[dtype] * amax
+        assert err <= tol, (case, (B, C, H, W), thr, scale, dtype, err, tol)

@@ -126,6 +126,7 @@ FUSED_CAST = True   # own GEMM: fp32 activations (autocast) are rounded to the c
 PRESCALE_Q = True   # own fused q/k/v GEMM: q leaves its epilogue as Q * attn.scale * log2(e) (still one rounding)
 
 
+FOLD_MIN_REF_TOKENS = 8   # reference token axes shorter than this get their AdaIN applied to V (one pass) instead of folded into the kernel
 FUSED_STATS = True  # own fused q/k/v GEMM: the token statistics of its V third (AdaIN) are its workgroups' tail, no pass over V
 
 
@@ -471,6 +472,14 @@ class SharedAttnProcessor(nn.Module):
                 else:
                     affine = _ops.adain_stats(value, ref_v, heads=attn.heads)
         _same_16bit(query, key, value, ref_k, ref_v)
+        if affine is not None and ref_v.shape[2] < FOLD_MIN_REF_TOKENS:
+            # a handful of reference tokens: a channel whose few values lie ulps apart gets a ratio in the thousands, and the
+            # fold's a * sum(p~ v) + b * sum(p) would amplify the 16-bit rounding of P by a * |mean|.  Here the
+            # renormalised V is formed once (ir_adain_apply, fp32 arithmetic, one rounding - what the reference's adain()
+            # does, attn_processors.py:7-18) and the attention runs without an affine.  Never taken by the model's own axes (>= 256).
+            ref_v = _ops.adain_apply(ref_v, affine[0], affine[1], heads=attn.heads)
+            affine = None
+            ref_valid = None       # a zero-filled reference's V is the style mean now, not zero: its tiles are walked
 
         want_probs = bool(self.save_self_attentions)
         want_mass = bool(getattr(self, "save_attention_mass", False))

@@ -497,6 +497,47 @@ def test_randomised_shape_sweep(ops):
         _check(out, ref, dtype, f"sweep case {case}: B{B} H{H} Lq{Lq} N{N} Lr{Lr} inc{inc} ad{ad}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["f16", "bf16"])
+@pytest.mark.parametrize("L", [2, 3, 5, 7])
+def test_processor_with_a_handful_of_reference_tokens_applies_adain_to_v(ops, dtype, L, monkeypatch):
+    """reference token axes shorter than 8 (never the model's own): channels whose few values lie one or two 16-bit steps apart get
+    AdaIN ratios in the hundreds, where the FOLDED form would amplify the rounding of P (the random sweep of
+    ``ir_shared_attn_fwd`` keeps AdaIN to >= 8 tokens for that reason).  The processor therefore applies AdaIN to V there
+    (``ir_adain_apply``) and runs the attention without an affine - what the reference's ``adain`` does (attn_processors.py:7-18,
+    :242-246) - and is held to the ordinary tolerance against the oracle's port of the reference operator sequence."""
+    from face_replace.models.attn_processors import SharedAttnProcessor
+    from instantrestore_amd.attention import Attention
+    import instantrestore_amd.attn_processors as ap
+    calls = []
+    real = ap._ops.adain_apply
+    monkeypatch.setattr(ap._ops, "adain_apply", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    torch.manual_seed(L)
+    B, H, N = 2, 2, 3
+    C = H * 64
+    attn = Attention(query_dim=C, heads=H, dim_head=64, processor=SharedAttnProcessor(self_attn_idx=0, use_adain=True, train_input=True)).cuda()
+    hidden = torch.randn(B, L, C, device="cuda")
+    rk = torch.randn(B, N, L, C, device="cuda").to(dtype)
+    rv = torch.randn(B, N, L, C, device="cuda").to(dtype)
+    # half of the channels nearly constant over the tokens: a base value plus zero, one or two steps of the 16-bit grid
+    step = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    base = torch.randn(B, N, 1, C // 2, device="cuda") * 0.5 + 1.0
+    rv[..., : C // 2] = (base + step * torch.randint(0, 3, (B, N, L, C // 2), device="cuda")).to(dtype)
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        out = attn(hidden, ref_keys=[rk], ref_values=[rv])
+    assert len(calls) == 1, "the short reference axis did not take the applied-to-V path"
+    r = lambda t: t.detach().to(dtype).float().cpu()
+    ref = O.shared_attn_processor_port(r(hidden), r(attn.to_q.weight), r(attn.to_k.weight), r(attn.to_v.weight), r(attn.to_out[0].weight),
+                                       r(attn.to_out[0].bias), rk.float().cpu(), rv.float().cpu(), H, use_adain=True, train_input=True)
+    err = float((out.float().cpu() - ref).abs().max())
+    bound = TOL[dtype] * max(1.0, float(ref.abs().max()))
+    assert torch.isfinite(out).all() and err <= bound, (err, bound)
+    # ... and with 8 tokens the fold is back (no applied pass)
+    calls.clear()
+    with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+        attn(torch.randn(B, 8, C, device="cuda"), ref_keys=[torch.randn(B, N, 8, C, device="cuda").to(dtype)], ref_values=[torch.randn(B, N, 8, C, device="cuda").to(dtype)])
+    assert not calls
+
+
 def test_randomised_modes_every_product_kernel(ops):
     """seeded sweep over the MODES of ``ir_shared_attn_fwd`` (IR_SWEEP_CASES / IR_SWEEP_SEED / IR_SWEEP_MAXLQ / IR_SWEEP_MAXLR widen it):
     every product kernel the mode admits (default dispatch and each tuning), plain or pre-scaled Q, q / k / v as the strided

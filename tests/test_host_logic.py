@@ -165,7 +165,11 @@ def test_valid_counts_travel_from_the_harvest_to_the_kernel_call(shim):
                  cross_attention_kwargs={"ref_keys": keys, "ref_values": vals, "ref_valid": valid}).sample
     assert torch.isfinite(y).all()
     calls = [c[1] for c in shim.CALLS if c[0] == "shared_attention"]
-    assert sum(1 for c in calls if c["valid_refs"] == [2, 1]) == 9            # the nine shared layers, told the counts
+    # the shared layers are told the counts - except the three whose reference axis has 2 x 2 = 4 tokens on this 8 x 8 latent: below
+    # FOLD_MIN_REF_TOKENS the processor applies AdaIN to V (ir_adain_apply) instead of folding it, the zero-filled references' V is
+    # then the style mean, not zero, and the promise no longer holds for that call
+    assert sum(1 for c in calls if c["valid_refs"] == [2, 1]) == 6 and sum(1 for c in calls if c["valid_refs"] is None and c["n_refs"] == N) == 3
+    assert sum(1 for c in shim.CALLS if c[0] == "adain_apply") == 3
     assert all(c["valid_refs"] is None for c in calls if c["n_refs"] == 0)    # plain / cross attention: never
     m = shared[0].attention_mass
     assert m.shape[0] == B and m.shape[-1] == N + 1 and float((m.sum(-1) - 1).abs().max()) < 1e-5

@@ -30,7 +30,7 @@ def test_capture_harvest_shared_pipeline_on_random_shapes():
     worst = 0.0
     for case in range(int(os.environ.get("IR_PROC_FUZZ_CASES", "16"))):
         B, N, H = int(rng.integers(1, 4)), int(rng.integers(1, 6)), int(rng.choice([1, 2, 3, 5]))
-        L = int(rng.choice([64, 128, 192, 320, 512, 768, 100, 200, 77 * 2]))
+        L = int(rng.choice([64, 128, 192, 320, 512, 768, 100, 200, 77 * 2, 5, 7]))    # 5, 7: below FOLD_MIN_REF_TOKENS (AdaIN applied to V)
         dtype = [torch.bfloat16, torch.float16][case % 2]
         train_input, use_adain = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
         stats_mode = int(rng.integers(0, 3))              # 0: no ref_stats, 1: harvested statistics (partials where possible), 2: finished pairs

@@ -355,7 +355,7 @@ def _pmc_traffic_bytes():
         return None
 
 
-def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=28.0, reps=3):
+def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=28.0, reps=3, dtype=None, dev=None):
     """oracle port (torch-CPU fp32, the reference's operator sequence) on the host cores: one identity through the same
     9 + 9 layers.  SURVEY 8d: ALL nine layer shapes (three per class, each with its own weights and activations, not one
     counted three times), 1 warm-up per class + the median of ``reps`` timed passes per layer for the configuration's own
@@ -367,9 +367,11 @@ def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=28.0, reps=3):
     torch.manual_seed(seed)
     cores = torch.get_num_threads()
 
+    r16 = (lambda t: t.to(dtype).float()) if dtype is not None else (lambda t: t)   # values the device path can hold exactly
+
     def make_layer(L, C):
-        w = [torch.randn(C, C) / C ** 0.5 for _ in range(4)]
-        return dict(w=w, bo=torch.zeros(C), h_ref=torch.randn(N, L, C), h_main=torch.randn(1, L, C))
+        w = [r16(torch.randn(C, C) / C ** 0.5) for _ in range(4)]
+        return dict(w=w, bo=torch.zeros(C), h_ref=r16(torch.randn(N, L, C)), h_main=r16(torch.randn(1, L, C)))
 
     def one_pass(ly, H, adain, t_in):
         w, bo = ly["w"], ly["bo"]
@@ -378,14 +380,44 @@ def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=28.0, reps=3):
         O.shared_attn_processor_port(ly["h_ref"], w[0], w[1], w[2], w[3], bo, None, None, H)       # K/V capture over the N reference token sets
         kr = torch.nn.functional.linear(ly["h_ref"], w[1]).reshape(1, N, L, C)
         vr = torch.nn.functional.linear(ly["h_ref"], w[2]).reshape(1, N, L, C)
-        O.shared_attn_processor_port(ly["h_main"], w[0], w[1], w[2], w[3], bo, kr, vr, H, adain, t_in)
-        return time.perf_counter() - t0
+        out = O.shared_attn_processor_port(ly["h_main"], w[0], w[1], w[2], w[3], bo, kr, vr, H, adain, t_in)
+        dt = time.perf_counter() - t0
+        if adain == use_adain and t_in == train_input:
+            ly["port_out"] = out          # kept for the deviation report below (the oracle as the CHECKER of the device path)
+        return dt
+
+    def device_deviation(ly, H):
+        """the same layer pair through the product path (K/V-capturing processor -> harvest -> shared processor under autocast)
+        on the GPU, against the port's fp32 result: SURVEY 8d's "max-abs deviation vs the CPU restatement per dtype" """
+        from types import SimpleNamespace
+        from face_replace.models.attn_processors import AttnProcessor, SharedAttnProcessor
+        from instantrestore_amd.attention import Attention
+        from instantrestore_amd.kv_harvest import harvest_reference_kv
+        C = ly["h_main"].shape[2]
+
+        def mk(proc):
+            a = Attention(query_dim=C, heads=H, dim_head=64, processor=proc)
+            with torch.no_grad():
+                for lin, w in zip((a.to_q, a.to_k, a.to_v, a.to_out[0]), ly["w"]):
+                    lin.weight.copy_(w)
+                a.to_out[0].bias.zero_()
+            return a.to(dev)
+        cap, main = mk(AttnProcessor()), mk(SharedAttnProcessor(self_attn_idx=0, use_adain=use_adain, train_input=train_input))
+        fake = SimpleNamespace(attn_processors={"up_blocks.1.attentions.0.transformer_blocks.0.attn1.processor": cap.processor})
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+            cap(ly["h_ref"].to(dev))
+            keys, values = harvest_reference_kv(fake, N, [N])[:2]
+            out = main(ly["h_main"].to(dev), ref_keys=keys, ref_values=values)
+        ref = ly["port_out"]
+        return float((out.float().cpu() - ref).abs().max()), float(ref.abs().max())
 
     spent = 0.0
     per_layer, other, reps_done = [], [], []
+    all_layers = []
     classes = layer_classes(px)
     for ci, (L, C, H) in enumerate(classes):
         layers3 = [make_layer(L, C) for _ in range(3)]
+        all_layers.extend(layers3)
         spent += one_pass(layers3[0], H, use_adain, train_input)            # warm-up of the class (allocator, thread pool)
         for ly in layers3:
             times = []
@@ -408,11 +440,29 @@ def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=28.0, reps=3):
             other.append(dt)
     t_total = sum(per_layer)
     t_other = sum(t for t in other if t is not None) if all(t is not None for t in other) else None
+    deviation = None
+    if dtype is not None and dev is not None:
+        try:
+            per_class, li = [], 0
+            for (L, C, H) in classes:
+                errs = [device_deviation(ly, H) for ly in all_layers[li:li + 3]]
+                li += 3
+                per_class.append({"L": L, "H": H, "max_abs_err": float("%.3e" % max(e for e, _ in errs)), "max_abs_ref": round(max(r for _, r in errs), 3)})
+            worst = max(c["max_abs_err"] / max(1.0, c["max_abs_ref"]) for c in per_class)
+            deviation = {"dtype": str(dtype).replace("torch.", ""), "layer_classes": per_class,
+                         "max_abs_err": max(c["max_abs_err"] for c in per_class), "worst_err_over_max_1_ref": float("%.3e" % worst),
+                         "note": "device path (capture processor -> harvest -> shared processor, autocast) against the fp32 port of the reference "
+                                 "operator sequence on the SAME 16-bit-representable weights and activations, one identity, all nine layers; "
+                                 "includes the 16-bit rounding of q / k / v, of the K/V stash and of the attention output on the device "
+                                 "(tests hold this level to 2 x 1e-3 (fp16) / 2 x 8e-3 (bf16) x max(1, |ref|))"}
+        except Exception as e:   # a report, never a reason to lose the line
+            deviation = {"error": repr(e)[:300]}
     return {
         "value": round(1.0 / t_total, 4) if t_total > 0 else None,
         "unit": "images/s",
         "cores": cores,
         "kind": "port",
+        "deviation_of_device_path": deviation,
         "other_setting": {"use_adain": False, "train_input": False,
                           "value": None if not t_other else round(1.0 / t_other, 4),
                           "seconds_per_layer": [None if t is None else round(t, 3) for t in other]},
@@ -1087,7 +1137,7 @@ def main():
                                     "projections, AdaIN statistics and launch gaps are in the time and not in the flops",
                             "kernel_classes_one_stream": kernel_class_breakdown(layers, B, N, max(2, args.steps // 2))}
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(N, px, train_input, use_adain, seed=99)
+            cpu = cpu_baseline(N, px, train_input, use_adain, seed=99, dtype=dtype, dev=dev)
     extras = None
     hung = False
     if not args.no_extras:

@@ -355,6 +355,48 @@ def _pmc_traffic_bytes():
         return None
 
 
+def live_pmc_traffic(timeout_s=150):
+    """OPT-IN (``IR_BENCH_LIVE_PMC=1``): HBM bytes per launch of the dominant kernel measured in THIS run - two counter-only
+    ``rocprofv3 --pmc`` passes (FETCH_SIZE, then WRITE_SIZE; never together with a trace domain beyond --kernel-trace) of
+    ``tools/prof_attn.py`` at the cfg-2 top-layer shape as child processes, each under its own timeout, with the guide's gfx950
+    correction (2 * FETCH_SIZE + WRITE_SIZE, KiB).  Off by default: counter collection is the one thing on this pool that has hung
+    a box before (the TCC_EA0 pass, NOTES 11.1), and the driver's bench run must never depend on it; the committed pass
+    (``traffic_static``) stays the default source.  Returns (bytes, detail) or (None, reason)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="ir_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", counter.lower(), "--",
+               sys.executable, os.path.join(REPO, "tools", "prof_attn.py"), "0", "3", "4096", "5", "1", "1", "1"]
+        import signal
+        proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                start_new_session=True)
+        try:
+            log, _ = proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)      # the profiler AND the workload it spawned (its own session: exactly this group)
+            except OSError:
+                pass
+            proc.wait()
+            return None, "%s pass timed out after %d s" % (counter, timeout_s)
+        if proc.returncode != 0:
+            return None, "%s pass failed: %s" % (counter, (log or "")[-200:])
+        got = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if "shared_attn_fwd_w64" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    got.append(float(row["Counter_Value"]))
+        shutil.rmtree(out, ignore_errors=True)
+        if not got:
+            return None, "%s: no row of the kernel in the counter file" % counter
+        vals[counter] = sum(got) / len(got)
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), {"FETCH_SIZE_KiB": round(vals["FETCH_SIZE"], 1),
+                                                                          "WRITE_SIZE_KiB": round(vals["WRITE_SIZE"], 1), "launches": 3}
+
+
 def cpu_baseline(N, px, train_input, use_adain, seed, budget_s=28.0, reps=3, dtype=None, dev=None):
     """oracle port (torch-CPU fp32, the reference's operator sequence) on the host cores: one identity through the same
     9 + 9 layers.  SURVEY 8d: ALL nine layer shapes (three per class, each with its own weights and activations, not one
@@ -1136,6 +1178,14 @@ def main():
                             "note": "attention flops of the 9 capture + 9 shared layers / ms_per_step of the headline run; the "
                                     "projections, AdaIN statistics and launch gaps are in the time and not in the flops",
                             "kernel_classes_one_stream": kernel_class_breakdown(layers, B, N, max(2, args.steps // 2))}
+        if world == 1 and roof is not None and os.environ.get("IR_BENCH_LIVE_PMC") == "1" and roof.get("traffic") is not None:
+            live, detail = live_pmc_traffic()
+            roof["traffic_committed_pass"] = roof["traffic"]
+            if live is not None:
+                roof["traffic"], roof["traffic_static"], roof["traffic_live_detail"] = live, False, detail
+                roof["traffic_unit"] = "bytes/launch (PMC in THIS run: 2*FETCH_SIZE + WRITE_SIZE, two counter-only rocprofv3 passes of tools/prof_attn.py)"
+            else:
+                roof["traffic_live_error"] = detail
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(N, px, train_input, use_adain, seed=99, dtype=dtype, dev=dev)
     extras = None

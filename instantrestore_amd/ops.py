@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -151,9 +152,13 @@ _WS = {}
 
 
 def _workspace(device: torch.device) -> torch.Tensor:
-    """one scratch buffer per (device, stream): launches on one stream are ordered, so reuse is safe"""
+    """one scratch buffer per (device, stream, THREAD).  Launches on one stream are ordered, so one thread reuses its buffer
+    safely; but ``ir_shared_attn_fwd`` issues two launches per call (the kernel, then the merge of its K/V-range pieces through
+    this scratch), ctypes releases the GIL for the call, and threads that share a stream - torch's default stream is shared by
+    all threads - can interleave: A's kernel, B's kernel, A's merge would read B's pieces.  A buffer per thread removes the
+    hazard (69 MB each; tests/test_gpu_threads.py)."""
     key = (device.index, _RAW_STREAM(device.index) if _RAW_STREAM is not None and device.index is not None
-           else torch.cuda.current_stream(device).cuda_stream)
+           else torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(_lib.lib().ir_shared_attn_workspace_bytes() // 4, dtype=torch.float32, device=device)

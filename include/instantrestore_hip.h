@@ -124,7 +124,10 @@ typedef struct ir_shared_attn_args {
                                kernel on the same stream turns them into masses (the S masses of a row sum to exactly 1).  What
                                gradio_demo.py:119-127 reduces attention_probs to, with no second pass over Q and K
                                (ir_attn_segment_mass is that second pass, for callers that only kept the LSE).  Taken as
-                               differences of cumulative sums: absolute accuracy ~1e-6, not relative.  NULL = off. */
+                               differences of cumulative sums: absolute accuracy ~1e-6, not relative.  Column order: segment 0
+                               is the SELF segment when INCLUDE_SELF is set, so the reference demo's blocks idx 0..3 (which start
+                               at column 0) are mass[..., 0:4] - valid only when len_self == len_ref - and the per-REFERENCE
+                               masses are mass[..., INCLUDE_SELF:].  NULL = off. */
 } ir_shared_attn_args;
 
 /* values of ir_shared_attn_args.tuning (csrc/shared_attn_fwd.hip lists what each one is) */

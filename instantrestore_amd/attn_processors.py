@@ -378,7 +378,9 @@ class FaceIDAttnProcessor(nn.Module):
         self.is_self_attn = None
 
     def forward(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
-                ref_keys=None, ref_values=None, ref_events=None, ref_stats=None):  # ref_* accepted and ignored, like the reference
+                ref_keys=None, ref_values=None, ref_events=None, ref_stats=None, ref_valid=None):
+        # ref_* accepted and ignored, like the reference: the host forwards ONE cross_attention_kwargs dict to every processor
+        # (unet.py / diffusers), so whatever the harvest hands SharedAttnProcessor (ref_valid included) arrives here too
         st = _prologue(attn, hidden_states, encoder_hidden_states, attention_mask, temb)
         self.is_self_attn = encoder_hidden_states is None
         query = attn.to_q(st.hidden)
@@ -415,6 +417,10 @@ class SharedAttnProcessor(nn.Module):
         # every call also leaves ``attention_mass`` - fp32 (B, H, L, [self?] + N), the attention mass per K/V segment - which is what
         # gradio_demo.py:119-127 reduces ``attention_probs`` to (``probs[..., attn_size*idx : attn_size*(idx+1)].sum(-1)``), without
         # the (B, H, L, Lkv) tensor and without a second pass (``ir_shared_attn_args.seg_mass``, ABI v9).  Independent of ``save_self_attentions``, whose meaning is unchanged.
+        # COLUMN ORDER vs the reference's demo: gradio_demo.py slices blocks ``attn_size*idx`` for idx 0..3 starting at column 0.  With
+        # ``train_input`` the columns are [self, ref0, ref1, ...], so the demo's block 0 is the SELF segment and its last reference is
+        # never read.  Reference-parity ranking therefore uses ``attention_mass[..., 0:4]`` (meaningful only when Ls == Lr, which the
+        # model guarantees); ``attention_mass[..., int(train_input):]`` is the per-REFERENCE form (what the demo presumably meant).
         self.save_attention_mass = False
         self.attention_mass = None
 

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(PW * 64) attn_probs_lines_kernel(const AttnKPa
 #pragma unroll
       // nt (non-temporal, aux bit 1 on gfx940+): P is written once and never read here, K is re-read by every wave from L2 - the
       // streaming hint keeps the 6.7 GB of P from pushing K out of the 4-MiB L2s.  A/B of the cache-policy bits on one box, top
-      // layer (tools/_probs_aux_probe.py): plain 1.69-1.74 ms, nt 1.49-1.53, sc1 / sc0 sc1 (write-through) 1.70-1.74, sc1 nt
+      // layer (round-5 A/B driver, profiles/r5_probs_probe.txt): plain 1.69-1.74 ms, nt 1.49-1.53, sc1 / sc0 sc1 (write-through) 1.70-1.74, sc1 nt
       // 1.53; whole probe on the next box (profiles/r5_probs_probe.txt): 1.23 ms = 5.4 TB/s, L = 1024 0.26 -> 0.18 ms.
       // -DPROBS_STORE_AUX=<bits> rebuilds the A/B (1 sc0, 2 nt, 16 sc1).
 #ifndef PROBS_STORE_AUX

@@ -101,9 +101,13 @@ static __device__ __forceinline__ void ir_wave_col_stats(const T* __restrict__ y
     for (int hb = 0; hb < HB; ++hb) {
       const int head = (h0 + hb) < head_hi ? (h0 + hb) : (head_hi - 1);    // past the range: the last head again (not stored)
 #pragma unroll
-      // nt: served by the L2 this wave's stores went to, never by the CU's vector L1.  A plain load could hit a line another
-      // wave of this CU pulled into L1 BEFORE the stores (only possible when y's 128-B lines straddle the column ranges of
-      // two workgroups - the C ABI now refuses that for a statistics call - but the tail must not depend on it)
+      // These loads re-read what this workgroup's own waves just stored.  WHAT GUARANTEES FRESH DATA is the C ABI's alignment
+      // rule for a statistics call (c_abi.hip: y_ld * 2 % 128 == 0 and the statistics columns on 128-B line boundaries), under
+      // which no 128-B line of y is shared between the column ranges of two workgroups: a line this wave reads was written by
+      // this workgroup only, after the barrier, and was not in this CU's vector L1 before (stores write through and invalidate
+      // the line).  The `nt` hint is a STREAMING hint (do not keep the line), not a coherence control: on gfx942 / gfx950 a stale
+      // line already in L1 could still hit under it - bypassing L1 would take sc0 sc1 on the load or a buffer_inv sc1 before it.
+      // It is kept for its cache effect only (the lines are read once).
       for (int j = 0; j < 8; ++j) xs[hb][j] = __builtin_nontemporal_load((const u32x4*)(base + head * 64 + (int64_t)(rs + 8 * j) * y_ld));
     }
 #pragma unroll

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(8))) float f32x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -120,7 +122,7 @@ static __device__ __forceinline__ void buffer_load_lds16_async(i32x4 rsrc, unsig
 // addresses were sixteen (linear_skinny.hip).  Counts in vmcnt like any store; hipcc's own waits only get stricter.
 // Cache policy of the projection GEMMs' OUTPUT stores: non-temporal since round 5 (-DIR_LIN_STORE_NT=0 rebuilds the plain form).
 // Y is written once by the GEMM and is larger than the L2s for every big shape; without the hint its lines push the operand
-// panels out.  Same-box A/B over the twelve step shapes (tools/_lin_nt_ab.py, three alternations): 1.79 -> 1.71 ms per step of
+// panels out.  Same-box A/B over the twelve step shapes (round-5 A/B driver, three alternations; profiles/r5_gemm_probe_final.txt): 1.79 -> 1.71 ms per step of
 // GEMM time in isolation, 131072 x 960 x 320 with fp32 activations 121 -> 100 us; the two-stream step itself is within its noise
 // (7.06 vs 7.02 ms): under the power cap and beside the other stream's attention the GEMMs are not what the step waits for.
 #ifndef IR_LIN_STORE_NT
@@ -142,3 +144,22 @@ static __device__ __forceinline__ void ir_store_y(u32x4* p, u32x4 v) {
 }
 
 static __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Opt-in to more than 64 KiB of dynamic LDS (hipFuncAttributeMaxDynamicSharedMemorySize): the attribute belongs to
+// (function, CURRENT device) and setting it is idempotent.  Each launcher instantiation keeps one IrOncePerDevice (a static
+// of the template function): an atomic flag per device, no lock - a race between threads only repeats an idempotent call,
+// and a device index beyond the table makes the call on every launch.  This is the only state of the library that outlives
+// a call (round 6: atomics; rounds 3-5 used plain bools here).
+struct IrOncePerDevice {
+  std::atomic<unsigned char> done[64];
+};
+static inline hipError_t ir_opt_in_dynamic_lds(IrOncePerDevice& once, const void* fn, size_t bytes, int* device = nullptr) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+  if (device != nullptr) *device = dev;
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && once.done[dev].load(std::memory_order_acquire) != 0) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess && tracked) once.done[dev].store(1, std::memory_order_release);
+  return e;
+}

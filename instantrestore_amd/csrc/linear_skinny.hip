@@ -473,15 +473,10 @@ hipError_t launch_skinny2(const LinearKParams& p, int grid, hipStream_t s) {
   // fit while the bias stays under ~2 KiB, i.e. N <= 960; wider biased outputs run one workgroup per CU), 114 KiB with 8
   const size_t fixed = (size_t)2 * KS * SUB_BYTES + (size_t)NW * 64 * kSkinnyTPitch;
   const size_t dyn = fixed + (BIAS ? (size_t)p.N * sizeof(T) : 0);
-  static bool attr_set[64] = {};   // per instantiation and per device; idempotent (see the K = 640 launch below)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
-  if (!attr_set[dev]) {
-    hipError_t ea = hipFuncSetAttribute((const void*)linear_skinny_kernel<T, KS, BIAS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(fixed + (BIAS ? kLinearMaxBiasN * sizeof(T) : 0)));
-    if (ea != hipSuccess) return ea;
-    attr_set[dev] = true;
-  }
+  static IrOncePerDevice once;   // per instantiation (ir_common.h)
+  const hipError_t ea = ir_opt_in_dynamic_lds(once, (const void*)linear_skinny_kernel<T, KS, BIAS, NW>,
+                                              fixed + (BIAS ? kLinearMaxBiasN * sizeof(T) : 0));
+  if (ea != hipSuccess) return ea;
   hipLaunchKernelGGL((linear_skinny_kernel<T, KS, BIAS, NW>), dim3((unsigned)grid), dim3(NW * 64), dyn, s, p);
   return hipGetLastError();
 }
@@ -517,16 +512,9 @@ hipError_t launch(const LinearKParams& p0, hipStream_t s) {
     p.nsplit = nsplit;
     constexpr int KSH = 5;
     const size_t dyn = (size_t)2 * (2 * KSH) * SUB_BYTES + 2 * 4 * 8192;
-    // the opt-in to > 64 KiB of dynamic LDS belongs to the function ON THE CURRENT DEVICE: one flag per device
-    // (a process may hold tensors on several), idempotent, so a race between threads only repeats the call
-    static bool attr_set[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
-    if (!attr_set[dev]) {
-      hipError_t ea = hipFuncSetAttribute((const void*)linear_ksplit_kernel<T, KSH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-      if (ea != hipSuccess) return ea;
-      attr_set[dev] = true;
-    }
+    static IrOncePerDevice once;   // per instantiation (ir_common.h)
+    const hipError_t ea = ir_opt_in_dynamic_lds(once, (const void*)linear_ksplit_kernel<T, KSH>, dyn);
+    if (ea != hipSuccess) return ea;
     hipLaunchKernelGGL((linear_ksplit_kernel<T, KSH>), dim3((unsigned)(mblocks * nsplit)), dim3(512), dyn, s, p);
     return hipGetLastError();
   }

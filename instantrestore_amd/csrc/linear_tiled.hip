@@ -589,28 +589,26 @@ hipError_t launch_pp(const LinearKParams& p0, hipStream_t s) {
   LinearKParams p = p0;
   p.nsplit = walk_group_rows();
   constexpr size_t dyn = 2 * (size_t)(256 + 256) * 128 + 8 * 4096;   // two operand stages + the waves' output staging: all of LDS
-  static bool attr_set[64] = {};
-  static int n_cu[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
-  if (!attr_set[dev]) {
-    hipError_t ea = hipFuncSetAttribute((const void*)linear_tiled_pp_kernel<T, XF32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    if (ea != hipSuccess) return ea;
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    n_cu[dev] = cus;
-    attr_set[dev] = true;
+  static IrOncePerDevice once;            // per instantiation (ir_common.h)
+  static std::atomic<int> n_cu[64];       // compute units of each device, read once (0 = not read yet)
+  int dev = -1;
+  const hipError_t ea = ir_opt_in_dynamic_lds(once, (const void*)linear_tiled_pp_kernel<T, XF32>, dyn, &dev);
+  if (ea != hipSuccess) return ea;
+  int cus = (dev >= 0 && dev < 64) ? n_cu[dev].load(std::memory_order_relaxed) : 0;
+  if (cus <= 0) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev < 0 ? 0 : dev) != hipSuccess || cus <= 0) cus = 256;
+    if (dev >= 0 && dev < 64) n_cu[dev].store(cus, std::memory_order_relaxed);
   }
   const int MT = (p.M + 255) / 256, NTl = (p.N + 255) / 256;
   const int ntiles = MT * NTl;
   // More tiles than CUs: ONE workgroup per CU walks its share of the tiles, with the next tile's first stage in flight during
   // the epilogue (the epilogue is an HBM-write burst; a quarter of a K = 640 tile's life).  Round 3 measured this form equal to
   // one workgroup per tile and kept the latter for the dispatcher's balancing; re-measured in round 4 on the short-K shapes of
-  // the step it is 1-3 % ahead per GEMM (tools/_r4_persist.sh: 102.2 -> 99.3, 33.8 -> 32.6 us) and 0.6-0.8 % on the whole
+  // the step it is 1-3 % ahead per GEMM (round-4 A/B, NOTES 10.2: 102.2 -> 99.3, 33.8 -> 32.6 us) and 0.6-0.8 % on the whole
   // two-stream step (7.019 -> 6.973 ms, three interleaved pairs), 0.2-0.6 % on one stream: the default since.
   // IR_LIN_PERSISTENT=0 restores one workgroup per tile (A/B).
   static const bool persistent = [] { const char* e = getenv("IR_LIN_PERSISTENT"); return e == nullptr || e[0] != '0'; }();
-  const int grid = (persistent && ntiles > n_cu[dev]) ? n_cu[dev] : ntiles;
+  const int grid = (persistent && ntiles > cus) ? cus : ntiles;
   hipLaunchKernelGGL((linear_tiled_pp_kernel<T, XF32>), dim3((unsigned)grid), dim3(512), dyn, s, p);
   return hipGetLastError();
 }
@@ -624,15 +622,9 @@ hipError_t launch_cfg(const LinearKParams& p0, hipStream_t s) {
   constexpr size_t epi = (size_t)WM * WN * MI * 32 * kTiledPitch;
   constexpr size_t dyn = KW * 2 * stage > epi ? KW * 2 * stage : epi;
   if (KW == 2 && ((p.K >> 6) & 1)) return hipErrorInvalidValue;   // the two K groups take whole, equal halves
-  static bool attr_set[64] = {};   // per instantiation and per device; idempotent
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
-  if (!attr_set[dev]) {
-    hipError_t ea = hipFuncSetAttribute((const void*)linear_tiled_kernel<T, WM, WN, MI, NI, XF32, ILV, KW>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    if (ea != hipSuccess) return ea;
-    attr_set[dev] = true;
-  }
+  static IrOncePerDevice once;   // per instantiation (ir_common.h)
+  const hipError_t ea = ir_opt_in_dynamic_lds(once, (const void*)linear_tiled_kernel<T, WM, WN, MI, NI, XF32, ILV, KW>, dyn);
+  if (ea != hipSuccess) return ea;
   const int MT = (p.M + BM - 1) / BM, NTl = p.N / BN;
   hipLaunchKernelGGL((linear_tiled_kernel<T, WM, WN, MI, NI, XF32, ILV, KW>), dim3((unsigned)(MT * NTl)), dim3(WM * WN * KW * 64), dyn, s, p);
   return hipGetLastError();

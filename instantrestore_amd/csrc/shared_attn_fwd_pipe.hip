@@ -691,7 +691,12 @@ __global__ void __launch_bounds__(NW * 64, ((ABL & 256) && !FOLD) ? 3 : 2) share
       *(f32x4*)(wo + 32 + 8 * g4 + 4 * hi) = x1;
     }
     if (hi == 0) {
-      p.ws_ml[prow * 2] = PRESC ? m_run / c2 : m_run;   // the combine kernel weighs pieces by raw-score maxima
+      // the combine kernel weighs pieces by raw-score maxima.  An EMPTY piece (valid_refs can leave fewer tiles than pieces were
+      // planned for) that does not own the zero-filled suffix holds nothing: it must not take part in the merge's maximum - the
+      // pre-scaled forms start their reference at 0, and a 0 beside real pieces whose maxima lie below -126 exponent units
+      // would flush every weight to zero
+      const bool empty_piece = NTILES == 0 && !(nref < p.N && piece == npiece - 1);
+      p.ws_ml[prow * 2] = empty_piece ? -INFINITY : (PRESC ? m_run / c2 : m_run);
       p.ws_ml[prow * 2 + 1] = l_fin;
     }
     return;

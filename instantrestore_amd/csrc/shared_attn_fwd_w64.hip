@@ -665,7 +665,9 @@ __global__ void __launch_bounds__(NW * 64, 2) shared_attn_fwd_w64_kernel(const A
         *(f32x4*)(wo + 32 + 8 * g4 + 4 * hi) = x1;
       }
       if (hi == 0) {
-        p.ws_ml[prow * 2] = m_raw;
+        // an EMPTY piece that does not own the zero-filled suffix stays out of the merge's maximum (QS starts its reference at 0)
+        const bool empty_piece = NTILES == 0 && !(nref < p.N && piece == npiece - 1);
+        p.ws_ml[prow * 2] = empty_piece ? -INFINITY : m_raw;
         p.ws_ml[prow * 2 + 1] = l_fin;
       }
       return;
@@ -725,15 +727,9 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
   size_t dyn_lds = 0;
   if (QS) {
     dyn_lds = (size_t)2 * W64_RING * TILE_BYTES + (size_t)NW * 8192;   // K/V ring + the waves' Q fragments
-    static bool attr_set[64] = {};   // per instantiation and per device; idempotent, so a race only repeats the call
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, attr_set[0] = false;
-    if (!attr_set[dev]) {
-      hipError_t ea = hipFuncSetAttribute((const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, QS, ABL, MASS>,
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
-      if (ea != hipSuccess) return ea;
-      attr_set[dev] = true;
-    }
+    static IrOncePerDevice once;   // per instantiation (ir_common.h)
+    const hipError_t ea = ir_opt_in_dynamic_lds(once, (const void*)shared_attn_fwd_w64_kernel<T, FOLD, NW, QS, ABL, MASS>, dyn_lds);
+    if (ea != hipSuccess) return ea;
   }
   hipLaunchKernelGGL((shared_attn_fwd_w64_kernel<T, FOLD, NW, QS, ABL, MASS>), dim3(grid), dim3(NW * 64), dyn_lds, s, p);
   hipError_t e = hipGetLastError();

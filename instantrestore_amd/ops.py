@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import os
+import collections
 import threading
 from typing import Optional, Tuple
 
@@ -148,7 +149,8 @@ def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adai
     return a
 
 
-_WS = {}
+_WS = threading.local()
+_WS_MAX_PER_THREAD = 4   # (device, stream) pairs a thread keeps scratch for; least recently used goes first
 
 
 def _workspace(device: torch.device) -> torch.Tensor:
@@ -156,13 +158,26 @@ def _workspace(device: torch.device) -> torch.Tensor:
     safely; but ``ir_shared_attn_fwd`` issues two launches per call (the kernel, then the merge of its K/V-range pieces through
     this scratch), ctypes releases the GIL for the call, and threads that share a stream - torch's default stream is shared by
     all threads - can interleave: A's kernel, B's kernel, A's merge would read B's pieces.  A buffer per thread removes the
-    hazard (69 MB each; tests/test_gpu_threads.py)."""
+    hazard (69 MB each; tests/test_gpu_threads.py).
+
+    Bounded (round 6): the buffers live in ``threading.local()`` - they are released with their thread, so a server that
+    spawns a thread per request does not accumulate them - and a thread keeps at most ``_WS_MAX_PER_THREAD`` (device, stream)
+    pairs, least recently used evicted.  An evicted buffer goes back to torch's caching allocator, which keeps it off other
+    streams until the work queued on its stream has run (``record_stream``)."""
     key = (device.index, _RAW_STREAM(device.index) if _RAW_STREAM is not None and device.index is not None
-           else torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
-    ws = _WS.get(key)
+           else torch.cuda.current_stream(device).cuda_stream)
+    cache = getattr(_WS, "cache", None)
+    if cache is None:
+        cache = _WS.cache = collections.OrderedDict()
+    ws = cache.get(key)
     if ws is None:
         ws = torch.empty(_lib.lib().ir_shared_attn_workspace_bytes() // 4, dtype=torch.float32, device=device)
-        _WS[key] = ws
+        ws.record_stream(torch.cuda.current_stream(device))
+        cache[key] = ws
+        while len(cache) > _WS_MAX_PER_THREAD:
+            cache.popitem(last=False)
+    else:
+        cache.move_to_end(key)
     return ws
 
 

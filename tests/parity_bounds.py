@@ -1,0 +1,84 @@
+"""The two bounds every oracle comparison of the fused attention is held to (round 6).
+
+STATED tolerance (what DESIGN.md promises a caller), against the float64 oracle / its fp32 port
+evaluated on the same 16-bit-rounded inputs:
+
+    fp16: max|O - O_ref| <= 1e-3 * max(1, max|O_ref|)
+    bf16: max|O - O_ref| <= 8e-3 * max(1, max|O_ref|)          (one bf16 ulp at 1.0 is 7.8e-3)
+
+REGRESSION bound (what the kernels deliver, with a margin of about 2x over the worst case observed on the whole GPU
+suite): the stated tolerance scales by max(1, |O|) while |O| is 0.15 ... 0.5 on N(0,1) activations, which left a 10-14x
+margin in which a lost K/V tile - 0.3 % of the probability mass at Lkv = 20 480 - would pass in bf16
+(tests/test_gpu_lost_tile.py shows that the regression bound catches it):
+
+    fp16: max|O - O_ref| <= 2e-4 * max(1, max|O_ref|)
+    bf16: max|O - O_ref| <= 2^-8 * max|O_ref| + 2e-4            (half an ulp of the output rounding is 2^-9 |O|; the 16-bit
+                                                                 probabilities add about as much before it)
+
+`factor` scales BOTH (e.g. tuning 11's extra rounding of Q: 2).  `reg_factor` scales the regression bound only and is given,
+with its reason, by the few callers whose inputs are outside N(0,1) activations (peaky logits, massive activations).
+
+IR_PARITY_LOG=<file> appends one JSON record per comparison (the distribution behind the constants above);
+IR_PARITY_SOFT=1 records regression-bound violations there without failing (calibration runs only - never set by the driver).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def stated_bound(dtype, ref_max, factor=1.0):
+    return factor * TOL[dtype] * max(1.0, ref_max)
+
+
+def regression_bound(dtype, ref_max, factor=1.0):
+    if dtype == torch.float16:
+        return factor * 2e-4 * max(1.0, ref_max)
+    return factor * (2.0 ** -8 * ref_max + 2e-4)
+
+
+def _to64(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().float().cpu().numpy().astype(np.float64)
+    return np.asarray(x, dtype=np.float64)
+
+
+def check_parity(out, ref, dtype, what, factor=1.0, reg_factor=1.0):
+    """asserts both bounds; returns the max-abs error"""
+    out, ref = _to64(out), _to64(ref)
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    assert np.isfinite(out).all(), f"{what}: non-finite output"
+    err = float(np.abs(out - ref).max()) if out.size else 0.0
+    rmax = float(np.abs(ref).max()) if ref.size else 0.0
+    stated = stated_bound(dtype, rmax, factor)
+    reg = regression_bound(dtype, rmax, factor * reg_factor)
+    log = os.environ.get("IR_PARITY_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(json.dumps({"what": str(what)[:200], "test": os.environ.get("PYTEST_CURRENT_TEST", "")[:200],
+                                "dtype": str(dtype).replace("torch.", ""), "err": err, "ref_max": rmax, "stated": stated,
+                                "regression": reg, "factor": factor, "reg_factor": reg_factor,
+                                "err_over_regression": err / reg if reg > 0 else None}) + "\n")
+    assert err <= stated, f"{what}: max|err| {err:.3e} > stated tolerance {stated:.3e} (max|ref| {rmax:.3f})"
+    if os.environ.get("IR_PARITY_SOFT") != "1":
+        assert err <= reg, (f"{what}: max|err| {err:.3e} is inside the stated tolerance {stated:.3e} but above the regression bound "
+                            f"{reg:.3e} (max|ref| {rmax:.3f}): the kernels deliver better than this - something regressed")
+    return err
+
+
+def check_before_rounding(out32, ref, what, bound=1e-3):
+    """north_star's literal number: the fp32 result BEFORE the output rounding (IR_FLAG_OUT_F32) within 1e-3 absolute"""
+    out32, ref = _to64(out32), _to64(ref)
+    assert out32.shape == ref.shape and np.isfinite(out32).all(), what
+    err = float(np.abs(out32 - ref).max())
+    log = os.environ.get("IR_PARITY_LOG")
+    if log:
+        with open(log, "a") as f:
+            f.write(json.dumps({"what": "f32:" + str(what)[:200], "test": os.environ.get("PYTEST_CURRENT_TEST", "")[:200],
+                                "dtype": "f32_before_rounding", "err": err, "ref_max": float(np.abs(ref).max()), "stated": bound,
+                                "regression": bound, "err_over_regression": err / bound}) + "\n")
+    assert err <= bound, f"{what}: max|err| before the output rounding {err:.3e} > {bound:.1e} (max|ref| {np.abs(ref).max():.3f})"
+    return err

@@ -3,13 +3,15 @@ classes), cfg 4 (B = 8, N = 8) and cfg 5 (B = 16, 1024 px, fp16) launched with t
 remap and the piece count at the real work-item count are part of what is compared - in the forms the processors launch
 (pre-scaled Q + AdaIN fold for the shared layers, plain self-attention over the B * N reference token sets for the capture
 layers).  Sampled query rows of the FIRST and LAST identity, every head (so the first and last head of each), against the
-oracle's fp32 CPU port on that identity's full K/V.  Tolerance (floating point, as everywhere): 1e-3 max(1, |O|) fp16,
-8e-3 max(1, |O|) bf16."""
+oracle's fp32 CPU port on that identity's full K/V.  Tolerance (floating point, as everywhere; tests/parity_bounds.py): the stated
+1e-3 max(1, |O|) fp16 / 8e-3 max(1, |O|) bf16 AND the regression bound 2e-4 max(1, |O|) fp16 / 2^-8 |O| + 2e-4 bf16; the bf16
+cases also run with fp32 output and meet north_star's literal 1e-3 before the output rounding (round 6)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import shared_attn_oracle as O
+from parity_bounds import check_before_rounding, check_parity
 
 pytestmark = pytest.mark.gpu
 TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
@@ -28,12 +30,7 @@ def _rows(L):
 
 
 def _check(out, ref, dtype, what):
-    out = out.float().cpu().numpy().astype(np.float64)
-    ref = ref.numpy().astype(np.float64)
-    assert np.isfinite(out).all(), what
-    err = np.abs(out - ref).max()
-    bound = TOL[dtype] * max(1.0, np.abs(ref).max())
-    assert err <= bound, f"{what}: max|err| {err:.3e} > {bound:.3e} (max|ref| {np.abs(ref).max():.3f})"
+    check_parity(out, ref.numpy(), dtype, what)
 
 
 @pytest.mark.parametrize("cfg,B,N,L,H,dtype", CASES, ids=[f"{c[0]}-B{c[1]}N{c[2]}L{c[3]}" for c in CASES])
@@ -52,13 +49,24 @@ def test_shared_layer_at_the_configs_batch(cfg, B, N, L, H, dtype, train_input):
     out = ops.shared_attention(qs, k, v, rk, rv, heads=H, scale=0.125, include_self=train_input, adain=aff, q_prescaled=True)
     name = ops.shared_attention_kernel_name(qs, k, v, rk, rv, heads=H, scale=0.125, include_self=train_input, adain=aff, q_prescaled=True)
     rows = _rows(L)
+    refs = []
     for b in (0, B - 1):                                               # first and last identity: both ends of the item grid
         ref = O.shared_attention_port(q_eff[b:b + 1, rows.cuda()].cpu(), k[b:b + 1].float().cpu(), v[b:b + 1].float().cpu(),
                                       rk[b:b + 1].float().cpu(), rv[b:b + 1].float().cpu(), H, 0.125, use_adain=True,
                                       train_input=train_input)
         _check(out[b:b + 1, rows.cuda()], ref, dtype, f"{cfg} shared L={L} identity {b} ({name})")
+        refs.append(ref)
     out2 = ops.shared_attention(qs, k, v, rk, rv, heads=H, scale=0.125, include_self=train_input, adain=aff, q_prescaled=True)
     assert torch.equal(out, out2)
+    if dtype == torch.bfloat16:
+        # north_star's literal "<= 1e-3 max-abs deviation": met by the SAME kernel's result before its rounding to bf16
+        # (IR_FLAG_OUT_F32; half a bf16 ulp at |O| = 0.5 is already 9.8e-4)
+        out32 = ops.shared_attention(qs, k, v, rk, rv, heads=H, scale=0.125, include_self=train_input, adain=aff, q_prescaled=True,
+                                     out_dtype=torch.float32)
+        assert out32.dtype == torch.float32
+        for b, ref in zip((0, B - 1), refs):
+            check_before_rounding(out32[b:b + 1, rows.cuda()], ref.numpy(), f"{cfg} shared L={L} identity {b} fp32 out ({name})")
+        assert torch.equal(out32.to(dtype), out)                        # ... and rounding it gives the bf16 result, bit for bit
 
 
 @pytest.mark.parametrize("cfg,B,N,L,H,dtype", CASES, ids=[f"{c[0]}-B{c[1]}N{c[2]}L{c[3]}" for c in CASES])
@@ -74,7 +82,14 @@ def test_capture_layer_at_the_configs_batch(cfg, B, N, L, H, dtype):
     q_eff = qs.float() / (0.125 * LOG2E)
     out = ops.shared_attention(qs, k, v, heads=H, scale=0.125, include_self=True, q_prescaled=True)
     rows = _rows(L)
+    refs = []
     for s in (0, S - 1):
         ref = O.shared_attention_port(q_eff[s:s + 1, rows.cuda()].cpu(), k[s:s + 1].float().cpu(), v[s:s + 1].float().cpu(), None, None,
                                       H, 0.125)
         _check(out[s:s + 1, rows.cuda()], ref, dtype, f"{cfg} capture L={L} token set {s}")
+        refs.append(ref)
+    if dtype == torch.bfloat16:
+        out32 = ops.shared_attention(qs, k, v, heads=H, scale=0.125, include_self=True, q_prescaled=True, out_dtype=torch.float32)
+        for s, ref in zip((0, S - 1), refs):
+            check_before_rounding(out32[s:s + 1, rows.cuda()], ref.numpy(), f"{cfg} capture L={L} token set {s} fp32 out")
+        assert torch.equal(out32.to(dtype), out)

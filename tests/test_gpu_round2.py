@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import shared_attn_oracle as O
+from parity_bounds import check_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -260,10 +261,7 @@ def test_prescaled_q_contract(variant, dtype, shape):
                                         adain=aff, return_lse=True, q_prescaled=True)
     finally:
         ops.set_attn_variant(0)
-    tol = {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
-    o = out[:, rows].float().cpu().numpy().astype(np.float64)
-    assert np.isfinite(o).all()
-    assert np.abs(o - ref).max() <= tol * max(1.0, np.abs(ref).max()), np.abs(o - ref).max()
+    check_parity(out[:, rows], ref, dtype, "pre-scaled Q contract")
     qh = O.head_to_batch_dim_np(q_equiv, H)
     ek, _ = O.extended_kv_np(f(k), f(v), f(rk), f(rv), H, False, inc)
     sc = np.matmul(qh, ek.transpose(0, 2, 1)) * 0.125
@@ -320,10 +318,7 @@ def test_reference_checked_after_the_exponentials(variant, case, dtype):
     finally:
         ops.set_attn_variant(0)
     assert {13: "w64", 11: "pipe", 18: "pipe"}[variant] in name, name
-    tol = {torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
-    o = out[:, rows].float().cpu().numpy().astype(np.float64)
-    assert np.isfinite(o).all()
-    assert np.abs(o - ref).max() <= tol * max(1.0, np.abs(ref).max()), np.abs(o - ref).max()
+    check_parity(out[:, rows], ref, dtype, f"reference checked after the exponentials ({name})")
     qh = O.head_to_batch_dim_np(q_equiv, H)
     ek, _ = O.extended_kv_np(f(k), f(v), f(rk), f(rv), H, False, True)
     sc = np.matmul(qh, ek.transpose(0, 2, 1)) * 0.125

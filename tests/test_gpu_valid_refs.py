@@ -12,6 +12,7 @@ import pytest
 import torch
 
 from oracle import shared_attn_oracle as O
+from parity_bounds import check_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -84,7 +85,7 @@ def test_closed_form_matches_the_oracle_on_zero_filled_references(ops, case, ada
     got = _np64(out)
     assert np.isfinite(got).all()
     bound = TOL[dtype] * max(1.0, np.abs(ref).max())
-    assert np.abs(got - ref).max() <= bound, (np.abs(got - ref).max(), bound)
+    check_parity(got, ref, dtype, "valid_refs closed form vs the oracle on the zero-filled tensors")
     walked, lse_w, _, _ = _run(ops, q, k, v, rk, rv, valid, H, inc, adain, pass_valid=False)
     assert np.abs(got - _np64(walked)).max() <= 2 * bound
     # the LSE carries the zero keys too: logsumexp over ALL columns of the zero-filled problem
@@ -104,7 +105,7 @@ def test_cfg4_top_layer_four_of_eight_references_valid(ops, adain, dtype):
     ref = O.shared_attention_np(_np64(q)[:, rows], _np64(k), _np64(v), _np64(rkz), _np64(rvz), H, 0.125, adain, True)
     got = _np64(out)[:, rows]
     bound = TOL[dtype] * max(1.0, np.abs(ref).max())
-    assert np.abs(got - ref).max() <= bound, (np.abs(got - ref).max(), bound)
+    check_parity(got, ref, dtype, "valid_refs closed form vs the oracle on the zero-filled tensors")
     walked, _, _, _ = _run(ops, q, k, v, rk, rv, valid, H, True, adain, pass_valid=False)
     assert np.abs(_np64(out) - _np64(walked)).max() <= 2 * bound
 

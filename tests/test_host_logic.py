@@ -177,6 +177,35 @@ def test_valid_counts_travel_from_the_harvest_to_the_kernel_call(shim):
     assert float(m[1, ..., 2:].min()) > 0
 
 
+def test_face_embed_processors_accept_the_harvests_valid_counts(shim):
+    """round 6: with ``condition_on_face_embeds`` every cross-attention is a ``FaceIDAttnProcessor`` and receives the SAME
+    ``cross_attention_kwargs`` as the shared layers (unet.py forwards one dict to every processor) - ``ref_valid`` included"""
+    from face_replace.models.attn_processors import (FaceIDAttnProcessor, SharedAttnProcessor, register_attention_processor,
+                                                     register_attention_processor_kv_unet)
+    from instantrestore_amd.kv_harvest import harvest_reference_kv
+    from instantrestore_amd.unet_host import AttnTopologyUNet
+    mk = lambda seed: AttnTopologyUNet(block_out_channels=(64, 128, 128, 128), attention_head_dim=(1, 2, 2, 2),
+                                       cross_attention_dim=32, seed=seed)
+    kv_unet, unet = mk(5), mk(6)
+    kv_unet.set_attn_processor({n: SharedAttnProcessor(self_attn_idx=None) for n in kv_unet.attn_processors})
+    register_attention_processor_kv_unet(kv_unet)
+    register_attention_processor(unet, SimpleNamespace(use_adain=True, train_input=True, condition_on_face_embeds=True))
+    face = [p for p in unet.attn_processors.values() if type(p) == FaceIDAttnProcessor]
+    assert len(face) == 16
+    B, N, S = 2, 3, 8
+    with torch.no_grad():
+        kv_unet(torch.randn(B * N, 4, S, S), None, encoder_hidden_states=torch.randn(B * N, 5, 32))
+        keys, vals, valid = harvest_reference_kv(kv_unet, N, [2, 1], with_valid=True)
+        del shim.CALLS[:]
+        # the face embedding stands where the text states stand (model.py hands (B, 1, 512) embeddings to the cross-attentions)
+        y = unet(torch.randn(B, 4, S, S), None, encoder_hidden_states=torch.randn(B, 1, 512),
+                 cross_attention_kwargs={"ref_keys": keys, "ref_values": vals, "ref_valid": valid}).sample
+    assert torch.isfinite(y).all()
+    assert all(p.is_self_attn is False for p in face)
+    calls = [c[1] for c in shim.CALLS if c[0] == "shared_attention"]
+    assert sum(1 for c in calls if c["valid_refs"] == [2, 1]) == 6     # the shared layers still get the counts
+
+
 SHARED = [m for m in GOLDEN_MANIFEST if m["kind"] == "shared"]
 
 

@@ -1,4 +1,4 @@
-"""same-box interleaved A/B of the bench step: usage _ab_step.py <switch> ; switch in {ref_stats, own_gemm, fused_stats, x_stationary_rot, x_stationary_pp}
+"""same-box interleaved A/B of the bench step: usage gpu_ab_step.py <switch> ; switch in {ref_stats, own_gemm, fused_stats, x_stationary_rot, x_stationary_pp}
  fused_stats: AdaIN statistics as the tail of the q/k/v GEMMs (round 4) vs the standalone passes of round 3 (GRAPH=1: hipGraph replays)
  ref_stats: AdaIN content statistics from the capture layer (round 3) vs re-read in every shared layer
  own_gemm : this library's GEMMs for every projection vs F.linear for the shapes the vendor GEMM served before round 3"""

@@ -1,6 +1,6 @@
 """interleaved, SUSTAINED A/B of GEMM kernels on one shape: each variant runs back to back for `secs` (the board settles at its
 power cap within milliseconds; short bursts ride on the idle clock), `rounds` times in rotation.
-usage: _lin_ab_sustained.py M N K bias(0/1) fp32(0/1) kernel [kernel ...]"""
+usage: gpu_gemm_ab_sustained.py M N K bias(0/1) fp32(0/1) kernel [kernel ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -138,6 +138,8 @@ typedef struct ir_shared_attn_args {
 #define IR_TUNE_W64X4 12
 #define IR_TUNE_W64X8 13
 #define IR_TUNE_PIPE32_EARLYQK 14
+#define IR_TUNE_W128 16            /* round 6: one wave per SIMD, 128 query rows per wave, hand-placed instruction stream; needs
+                                      IR_FLAG_Q_PRESCALED, segment lengths that are multiples of 64, no valid_refs / seg_mass */
 #define IR_TUNE_W64_ABL_FIRST 20 /* 20 ... : development builds (-DIR_ABLATIONS) only - energy / timing ablations of the 64-row kernel
                                     (WRONG results: one class of work removed per bit; tools/gpu_energy_probe.py).  Values 16 / 17
                                     (rounds 2-3: one-wave-per-SIMD and three-stage experiments) are retired. */

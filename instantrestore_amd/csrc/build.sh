@@ -6,8 +6,10 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${IR_OUT:-${HERE}/../libinstantrestore_hip.so}"
 BUILD_DIR="${IR_BUILD_DIR:-build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-SRCS=(linear_tiled.hip shared_attn_fwd.hip shared_attn_fwd_pipe.hip shared_attn_fwd_w64.hip attn_probs.hip adain.hip image_io.hip linear_skinny.hip bench_hooks.hip c_abi.hip)
+SRCS=(linear_tiled.hip shared_attn_fwd.hip shared_attn_fwd_pipe.hip shared_attn_fwd_w64.hip shared_attn_fwd_w128.hip attn_probs.hip adain.hip image_io.hip linear_skinny.hip bench_hooks.hip c_abi.hip)
 cd "${HERE}"
+# the hand-placed instruction stream of the 128-row attention kernel is generated (committed; regenerated here so it cannot go stale)
+python3 "${HERE}/w128/gen.py"
 OBJS=()
 pids=()
 mkdir -p "${BUILD_DIR}"
@@ -20,6 +22,9 @@ for s in "${SRCS[@]}"; do
   # the dump kernels exponentiate every MFMA result on the VALU: MFMA destinations in VGPRs (hipcc's default puts them in AGPRs
   # and copies each one out with v_accvgpr_read: 96 of 271 vector instructions per 64 x 64 tile, profiles/r5_pmc_probs.txt)
   [[ "$s" == attn_probs.hip ]] && extra+=(-mllvm -amdgpu-mfma-vgpr-form)
+  # round 6: the 128-rows-per-wave kernel (one wave per SIMD, hand-placed stream) is the default wherever the 64-row kernel was and
+  # the call is in its domain: same-box sustained A/B at cfg 2's top layer 0.709 vs 0.791 ms (profiles/r6_w128_ab.txt); IR_ATTN_W128=0 restores
+  [[ "$s" == shared_attn_fwd.hip ]] && extra+=(-DIR_W128_DEFAULT=${IR_W128_DEFAULT:-1})
   # resource remarks (registers, spills, scratch per kernel) go to <build dir>/<source>.remarks: tools/check_resources.py reads them
   "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Rpass-analysis=kernel-resource-usage "${extra[@]}" "$@" -c "$s" -o "$o" 2> "${BUILD_DIR}/${s%.hip}.remarks" &
   pids+=($!)

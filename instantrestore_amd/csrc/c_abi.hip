@@ -70,9 +70,11 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   p->include_self = inc ? 1 : 0;
   p->q_prescaled = (a->flags & IR_FLAG_Q_PRESCALED) ? 1 : 0;
   p->out_f32 = (a->flags & IR_FLAG_OUT_F32) ? 1 : 0;
-  if (p->q_prescaled && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q &&
+  if (p->q_prescaled && a->tuning != IR_TUNE_DEFAULT && a->tuning != IR_TUNE_W64X8 && a->tuning != IR_TUNE_W128 && a->tuning != IR_TUNE_PIPE32_PRESCALE_Q &&
       a->tuning != IR_TUNE_PIPE32_POSTCHECK && !(a->tuning >= IR_TUNE_W64_ABL_FIRST && a->tuning < IR_TUNE_W64_ABL_FIRST + 16))
-    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W64X8, PIPE32_PRESCALE_Q and PIPE32_POSTCHECK kernels only");
+    return fail(IR_ERR_UNSUPPORTED, "IR_FLAG_Q_PRESCALED is implemented by the W128, W64X8, PIPE32_PRESCALE_Q and PIPE32_POSTCHECK kernels only");
+  if (a->tuning == IR_TUNE_W128 && !p->q_prescaled)
+    return fail(IR_ERR_UNSUPPORTED, "IR_TUNE_W128 needs IR_FLAG_Q_PRESCALED");
   if (!p->q_prescaled && a->tuning == IR_TUNE_PIPE32_POSTCHECK)
     return fail(IR_ERR_UNSUPPORTED, "IR_TUNE_PIPE32_POSTCHECK needs IR_FLAG_Q_PRESCALED (its scores must already carry the reference)");
   p->tiles_self = inc ? (a->len_self + IR_KV_TILE - 1) / IR_KV_TILE : 0;
@@ -84,6 +86,8 @@ int build_attn_params(const ir_shared_attn_args* a, AttnKParams* p, bool need_ou
   if (a->workspace != nullptr && !aligned16(a->workspace)) return fail(IR_ERR_UNSUPPORTED, "workspace must be 16-byte aligned");
   p->ws = (float*)a->workspace;
   p->ws_bytes = a->workspace != nullptr ? (size_t)a->workspace_bytes : 0;
+  if (a->tuning == IR_TUNE_W128 && !ir_attn_w128_supports(*p))
+    return fail(IR_ERR_UNSUPPORTED, "IR_TUNE_W128 takes segment lengths that are multiples of 64 keys, no valid_refs and no seg_mass");
   const int64_t blocks = (int64_t)a->batch * a->heads * ((a->len_q + 127) / 128);
   if (blocks > 0x7fffffffLL) return fail(IR_ERR_UNSUPPORTED, "grid too large");
   return IR_OK;
@@ -106,6 +110,9 @@ const char* ir_shared_attn_kernel_name(const ir_shared_attn_args* args) {
   const int v = args->tuning & 31;
   const bool fold = p.aa != nullptr;
   const bool w64 = (v == 0 && ir_attn_default_is_w64(p)) || v == 13;
+  if ((v == 16 || (v == 0 && ir_attn_default_is_w128(p))) && ir_attn_w128_supports(p))
+    return fold ? "shared_attn_fwd_w128_kernel<128 rows/wave, one wave per SIMD, hand-placed stream, pre-scaled Q, AdaIN ratio-frame fold>"
+                : "shared_attn_fwd_w128_kernel<128 rows/wave, one wave per SIMD, hand-placed stream, pre-scaled Q>";
   if (p.q_prescaled) {   // the dispatch of ir_launch_shared_attn_fwd, restated for reporting
     if (w64) return fold ? "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, pre-scaled Q (reference through the MFMA C operand, checked after the exponentials), AdaIN ratio-frame fold>"
                          : "shared_attn_fwd_w64_kernel<64 rows/wave, 8 waves, pre-scaled Q (reference through the MFMA C operand, checked after the exponentials)>";

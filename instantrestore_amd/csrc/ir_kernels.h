@@ -103,6 +103,10 @@ hipError_t ir_launch_shared_attn_fwd_pipe_abl(const AttnKParams& p, int abl, hip
 hipError_t ir_launch_shared_attn_combine(const AttnKParams& p, int dtype, int qb, int rem, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64(const AttnKParams& p, int dtype, hipStream_t s);
 hipError_t ir_launch_shared_attn_fwd_w64x8(const AttnKParams& p, int dtype, hipStream_t s);
+// round 6: one wave per SIMD, 128 query rows per wave, hand-placed instruction stream (shared_attn_fwd_w128.hip)
+hipError_t ir_launch_shared_attn_fwd_w128(const AttnKParams& p, int dtype, hipStream_t s);
+bool ir_attn_w128_supports(const AttnKParams& p);   // pre-scaled Q, whole 64-key tiles, no valid_refs / seg_mass
+bool ir_attn_default_is_w128(const AttnKParams& p);
 #ifdef IR_ABLATIONS   // energy / timing ablations of the 64-row QS kernel (tuning values 20 + index; shared_attn_fwd_w64.hip)
 hipError_t ir_launch_shared_attn_fwd_w64_abl(const AttnKParams& p, int dtype, int index, hipStream_t s);
 int ir_w64_abl_count(void);

@@ -37,6 +37,12 @@
 #include "ir_common.h"
 #include "ir_kernels.h"
 
+#include <stdlib.h>
+
+#ifndef IR_W128_DEFAULT
+#define IR_W128_DEFAULT 0   // 1: the 128-row kernel is the default wherever the 64-row kernel was (set by build.sh once measured faster)
+#endif
+
 #ifdef IR_ABLATIONS   // the first, straight-line kernel (variants 1/2) and its timing ablations: development builds only
 namespace {
 
@@ -408,6 +414,7 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 
 // variant & 31 selects the kernel (per-call tuning field of ir_shared_attn_args; 0 = default dispatch, see
 // ir_attn_default_is_w64).  Product library:
+//   16 128 query rows per wave, ONE wave per SIMD, hand-placed instruction stream (shared_attn_fwd_w128.hip; pre-scaled Q only)
 //   13 64 query rows per wave, 8-wave (512-row) workgroups (shared_attn_fwd_w64.hip)     12 the same, 4 waves
 //   10 software-pipelined 32-row kernel, 4 waves, asm-issued LDS-DMA staging, lazy max (shared_attn_fwd_pipe.hip)
 //    7 the same with an exact (every-change) rescale
@@ -425,10 +432,10 @@ hipError_t launch_t(const AttnKParams& p, int nw, hipStream_t s) {
 bool ir_attn_variant_available(int variant) {
   const int base = variant & 31;
 #ifdef IR_ABLATIONS
-  return (base <= 18 && base != 8 && base != 15 && base != 16 && base != 17) || (base >= 20 && base < 20 + ir_w64_abl_count());
+  return (base <= 18 && base != 8 && base != 15 && base != 17) || (base >= 20 && base < 20 + ir_w64_abl_count());
 #else
   if ((variant >> 5) != 0) return false;
-  return base == 0 || base == 7 || (base >= 10 && base <= 14) || base == 18;   // 16 (SP64) and 17 (TP32): development builds, like 1-6, 8, 9, 15
+  return base == 0 || base == 7 || (base >= 10 && base <= 14) || base == 16 || base == 18;   // 16 (SP64) and 17 (TP32): development builds, like 1-6, 8, 9, 15
 #endif
 }
 
@@ -437,6 +444,15 @@ bool ir_attn_variant_available(int variant) {
 bool ir_attn_default_is_w64(const AttnKParams& p) {
   const long items512 = (long)p.B * p.H * ((p.Lq + 511) / 512);
   return p.Lq >= 4096 && (items512 >= 256 || p.ntiles >= 128);
+}
+
+// Round 6: where the 64-row kernel would run AND the call is in the 128-row kernel's domain (pre-scaled Q, whole tiles, no
+// valid_refs / seg_mass) the one-wave-per-SIMD kernel takes it.  IR_ATTN_W128=0 / 1 overrides the rule for A/B runs.
+bool ir_attn_default_is_w128(const AttnKParams& p) {
+  static const int env = [] { const char* e = getenv("IR_ATTN_W128"); return e == nullptr ? -1 : (e[0] == '0' ? 0 : 1); }();
+  if (env == 0) return false;
+  if (!ir_attn_w128_supports(p)) return false;
+  return env == 1 ? p.Lq >= 1024 : (IR_W128_DEFAULT != 0 && ir_attn_default_is_w64(p));
 }
 
 // ABI v9 (seg_mass): the forward kernels left, per row, the cumulative log-sum-exp c_0 <= c_1 <= ... <= c_{S-1} (= the row's LSE)
@@ -470,7 +486,7 @@ hipError_t ir_launch_shared_attn_fwd(const AttnKParams& p, int dtype, int varian
     // by-product of the 64-row and the pipelined 32-row kernels (every product kernel); the development-only experiments never learned it
     // (the 8-wave 64-row kernel and the 32-row kernel's two default forms carry the MASS instantiation: tuning 0, 11, 13, 14)
     const int b0 = variant & 31;
-    if ((variant >> 5) != 0 || !(b0 == 0 || b0 == 11 || b0 == 13 || b0 == 14)) return hipErrorInvalidValue;
+    if ((variant >> 5) != 0 || !(b0 == 0 || b0 == 11 || b0 == 13 || b0 == 14)) return hipErrorInvalidValue;   // (16 has no MASS form)
   }
   const hipError_t e = launch_attn_kernel(p, dtype, variant, s);
   if (e != hipSuccess || p.seg_cum == nullptr) return e;
@@ -504,7 +520,9 @@ static hipError_t launch_attn_kernel(const AttnKParams& p, int dtype, int varian
 #ifdef IR_ABLATIONS
   if (base >= 20) return ir_launch_shared_attn_fwd_w64_abl(p, dtype, base - 20, s);
 #endif
+  if (base == 16) return ir_launch_shared_attn_fwd_w128(p, dtype, s);   // (refuses what it does not cover)
   if (p.q_prescaled) {
+    if (base == 0 && ir_attn_default_is_w128(p)) return ir_launch_shared_attn_fwd_w128(p, dtype, s);
     if ((base == 0 && ir_attn_default_is_w64(p)) || base == 13) return ir_launch_shared_attn_fwd_w64x8(p, dtype, s);
     // the 32-row kernel's pre-scaled-Q form (no Q rounding of its own), with the row max of every tile.  Its
     // check-after-the-exponentials form (IR_TUNE_PIPE32_POSTCHECK, round 3) is parity-green and measures the SAME time

@@ -150,7 +150,7 @@ def _fill_args(q, k_self, v_self, ref_k, ref_v, heads, scale, include_self, adai
 
 
 _WS = threading.local()
-_WS_MAX_PER_THREAD = 4   # (device, stream) pairs a thread keeps scratch for; least recently used goes first
+_WS_MAX_PER_THREAD = 8   # unpinned (device, stream) pairs a thread keeps scratch for; least recently used goes first
 
 
 def _workspace(device: torch.device) -> torch.Tensor:
@@ -161,23 +161,33 @@ def _workspace(device: torch.device) -> torch.Tensor:
     hazard (69 MB each; tests/test_gpu_threads.py).
 
     Bounded (round 6): the buffers live in ``threading.local()`` - they are released with their thread, so a server that
-    spawns a thread per request does not accumulate them - and a thread keeps at most ``_WS_MAX_PER_THREAD`` (device, stream)
-    pairs, least recently used evicted.  An evicted buffer goes back to torch's caching allocator, which keeps it off other
-    streams until the work queued on its stream has run (``record_stream``)."""
+    spawns a thread per request does not accumulate them - and a thread keeps at most ``_WS_MAX_PER_THREAD`` UNPINNED
+    (device, stream) pairs, least recently used evicted.  A buffer handed out while its stream is being CAPTURED into a hipGraph
+    is pinned for the life of the thread: the graph replays with the raw pointer, long after this call (bench.py's captured step;
+    the first version of the bound evicted such a buffer and the replay faulted).  An evicted buffer goes back to torch's caching
+    allocator, which keeps it off other streams until the work queued on its stream has run (``record_stream``)."""
     key = (device.index, _RAW_STREAM(device.index) if _RAW_STREAM is not None and device.index is not None
            else torch.cuda.current_stream(device).cuda_stream)
     cache = getattr(_WS, "cache", None)
     if cache is None:
         cache = _WS.cache = collections.OrderedDict()
+        _WS.pinned = {}
+    ws = _WS.pinned.get(key)
+    if ws is not None:
+        return ws
+    capturing = torch.cuda.is_current_stream_capturing()
     ws = cache.get(key)
     if ws is None:
         ws = torch.empty(_lib.lib().ir_shared_attn_workspace_bytes() // 4, dtype=torch.float32, device=device)
-        ws.record_stream(torch.cuda.current_stream(device))
+        if not capturing:
+            ws.record_stream(torch.cuda.current_stream(device))
         cache[key] = ws
-        while len(cache) > _WS_MAX_PER_THREAD:
-            cache.popitem(last=False)
     else:
         cache.move_to_end(key)
+    if capturing:
+        _WS.pinned[key] = cache.pop(key)
+    while len(cache) > _WS_MAX_PER_THREAD:
+        cache.popitem(last=False)
     return ws
 
 
@@ -716,14 +726,14 @@ _TUNING = int(os.environ.get("IR_ATTN_VARIANT", "0") or 0)
 
 
 def tuning_supports_prescaled_q() -> bool:
-    """``IR_FLAG_Q_PRESCALED`` is implemented by the default dispatch and by the kernels it picks from (tuning 0, 11, 13, 18;
+    """``IR_FLAG_Q_PRESCALED`` is implemented by the default dispatch and by the kernels it picks from (tuning 0, 11, 13, 16, 18;
     the development build's ablations 20-28 take the flag explicitly); under any other A/B ``tuning`` the processors keep the plain q (the C ABI rejects the combination)"""
-    return _TUNING in (0, 11, 13, 18)
+    return _TUNING in (0, 11, 13, 16, 18)
 
 
 def set_attn_variant(variant: int) -> int:
     """tuning hook for benchmarks / A-B tests: the value goes into the per-call ``tuning`` field of the C ABI's
-    argument block (``IR_TUNE_*`` in include/instantrestore_hip.h; 0 = default dispatch, 13 / 12 = 64-row kernel in 8- / 4-wave workgroups, 10 / 14 = pipelined 32-row kernel, 11 = its
+    argument block (``IR_TUNE_*`` in include/instantrestore_hip.h; 0 = default dispatch, 16 = 128-row kernel (one wave per SIMD; pre-scaled Q only), 13 / 12 = 64-row kernel in 8- / 4-wave workgroups, 10 / 14 = pipelined 32-row kernel, 11 = its
     pre-scaled-Q form).  ``IR_ATTN_VARIANT=<n>`` in the environment sets the initial value.  Returns the previous one.
     The C library itself holds no such state."""
     global _TUNING

@@ -6,14 +6,18 @@ evaluated on the same 16-bit-rounded inputs:
     fp16: max|O - O_ref| <= 1e-3 * max(1, max|O_ref|)
     bf16: max|O - O_ref| <= 8e-3 * max(1, max|O_ref|)          (one bf16 ulp at 1.0 is 7.8e-3)
 
-REGRESSION bound (what the kernels deliver, with a margin of about 2x over the worst case observed on the whole GPU
-suite): the stated tolerance scales by max(1, |O|) while |O| is 0.15 ... 0.5 on N(0,1) activations, which left a 10-14x
-margin in which a lost K/V tile - 0.3 % of the probability mass at Lkv = 20 480 - would pass in bf16
-(tests/test_gpu_lost_tile.py shows that the regression bound catches it):
+REGRESSION bound (what the kernels deliver; calibrated on the whole GPU suite with IR_PARITY_LOG, 456 comparisons, round 6):
+the stated tolerance scales by max(1, |O|) while |O| is 0.15 ... 0.5 on N(0,1) activations, which left a 10-14x margin in
+which lost keys would pass in bf16 (tests/test_gpu_lost_tile.py shows what the regression bound catches and the stated
+tolerance does not).  The error of a 16-bit result has two parts that scale with the OUTPUT - half an ulp of the output
+rounding (2^-9 |O| bf16, 2^-12 ... 2^-11 |O| fp16) and the 16-bit probabilities ahead of P.V (about as much again when few
+keys carry a row) - and a part that does not (exp2, fp32 sums, the reference's rounding):
 
-    fp16: max|O - O_ref| <= 2e-4 * max(1, max|O_ref|)
-    bf16: max|O - O_ref| <= 2^-8 * max|O_ref| + 2e-4            (half an ulp of the output rounding is 2^-9 |O|; the 16-bit
-                                                                 probabilities add about as much before it)
+    bf16: max|O - O_ref| <= 1.25 * 2^-8  * max|O_ref| + 2e-4        (worst observed 1.12 * 2^-8 |O|;  2.0e-3 at |O| = 0.36)
+    fp16: max|O - O_ref| <= 1.25 * 2^-11 * max|O_ref| + 1.5e-4      (worst observed 1.10 * 2^-11 |O|; 3.7e-4 at |O| = 0.36)
+
+(The review's first proposal for fp16, 2e-4 max(1, |O|), is below the format's own rounding step once |O| > 0.8: half an
+fp16 ulp at 1.0 is 2.4e-4, at 4.0 it is 9.8e-4.)
 
 `factor` scales BOTH (e.g. tuning 11's extra rounding of Q: 2).  `reg_factor` scales the regression bound only and is given,
 with its reason, by the few callers whose inputs are outside N(0,1) activations (peaky logits, massive activations).
@@ -36,8 +40,8 @@ def stated_bound(dtype, ref_max, factor=1.0):
 
 def regression_bound(dtype, ref_max, factor=1.0):
     if dtype == torch.float16:
-        return factor * 2e-4 * max(1.0, ref_max)
-    return factor * (2.0 ** -8 * ref_max + 2e-4)
+        return factor * (1.25 * 2.0 ** -11 * ref_max + 1.5e-4)
+    return factor * (1.25 * 2.0 ** -8 * ref_max + 2e-4)
 
 
 def _to64(x):

@@ -47,3 +47,37 @@ _Z3foov: ; @foo
     assert name == "_Z3foov" and len(found) == 1
     (_, label), (n_mfma, scr) = next(iter(found.items()))
     assert label == ".LBB0_1" and n_mfma == 1 and len(scr) == 1 and "v1" in scr[0]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+def test_w128_kernel_keeps_the_compiler_out_of_the_accumulator_registers(tmp_path):
+    """shared_attn_fwd_w128.hip keeps its state between asm statements in accumulator registers the compiler does not know about
+    (O, the Q fragments, m / l / l_done): the ISA must show NO compiler-generated v_accvgpr_* / AGPR operand outside the asm
+    blocks, no scratch, no spill, 256 AGPRs and one wave per SIMD - otherwise a compiler copy into that range corrupts the state
+    silently (the guide's item 4 of 'what hipcc does not do for an asm statement')."""
+    import re
+    out = tmp_path / "w128.s"
+    src = os.path.join(ROOT, "instantrestore_amd", "csrc", "shared_attn_fwd_w128.hip")
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), src],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    inasm, cur, bad, kernels = False, None, [], set()
+    for line in open(out):
+        m = re.match(r"^(_ZN\S*shared_attn_fwd_w128_kernel\S*):", line)
+        if m:
+            cur = m.group(1)
+            kernels.add(cur)
+        if ";;#ASMSTART" in line:
+            inasm = True
+            continue
+        if ";;#ASMEND" in line:
+            inasm = False
+            continue
+        code = line.split(";")[0]
+        if cur and not inasm and (re.search(r"v_accvgpr|\ba\d+\b|a\[\d+", code) or "scratch_" in code):
+            bad.append((cur[-30:], line.strip()))
+    text = open(out).read()
+    assert len(kernels) == 4, kernels                                  # bf16 / f16 x fold / plain
+    assert not bad, bad[:10]
+    assert text.count(".vgpr_spill_count: 0") == 4 and text.count(".agpr_count:     256") == 4
+    assert text.count(".private_segment_fixed_size: 0") >= 4

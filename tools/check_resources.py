@@ -9,7 +9,7 @@ import re
 import subprocess
 import sys
 
-NO_SCRATCH = ("linear_tiled",)      # mangled-name substrings: scratch / spills are a build error for these kernels
+NO_SCRATCH = ("linear_tiled", "shared_attn_fwd_w128")     # mangled-name substrings: scratch / spills are a build error for these kernels
 
 
 def demangle(name):

@@ -30,7 +30,7 @@ def test_probability_dump_with_q_prescaled_and_a_split_launch(dtype):
         q, k, v, presc, _ = ap._project_qkv(attn, st)
     assert presc, "the own fused GEMM must hand the kernel a pre-scaled query at this shape"
     name = ops.shared_attention_kernel_name(q, k, v, rk, rv, heads=H, scale=attn.scale, include_self=True, q_prescaled=True)
-    assert "w64" in name and "pre-scaled" in name
+    assert ("w128" in name or "w64" in name) and "pre-scaled" in name     # round 6: the 128-row kernel where it applies
     probs = proc.attention_probs
     assert probs.shape == (B, H, L, 2 * L) and probs.dtype == dtype and torch.isfinite(out).all()
     rows = torch.arange(0, L, 97, device="cuda")

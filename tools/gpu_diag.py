@@ -22,7 +22,10 @@ def onehot_case(dtype, L, N, Lr, inc, variant):
     rv = vall[off:].reshape(1, N, Lr, 64) if N else None
     c = lambda t: None if t is None else t.to(dtype).cuda()
     ops.set_attn_variant(variant)
-    out = ops.shared_attention(c(q), c(k_self), c(v_self), c(rk), c(rv), heads=1, scale=0.125, include_self=inc)
+    presc = variant == 16        # the 128-row kernel (round 6) takes pre-scaled Q only
+    if presc:
+        q = q * (0.125 * 1.4426950408889634)
+    out = ops.shared_attention(c(q), c(k_self), c(v_self), c(rk), c(rv), heads=1, scale=0.125, include_self=inc, q_prescaled=presc)
     torch.cuda.synchronize()
     out = out.float().cpu()[0]
     want = vall[pi].to(dtype).float()

@@ -165,65 +165,79 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1,
     });
   };
 
-  // ---- the K/V walk: runs of consecutive tiles of one segment -----------------------------------------------------------------
-  {
-    int t = tile_begin;
-    bool first = true;
+  // ---- the K/V walk: runs of consecutive tiles of one segment ---------------------------------------------------------------
+  // The DMA stream runs across runs (stream v2): while a run computes its last tile, its last DMA slot fetches the FIRST tile
+  // of the next run (flags bit 1; the next segment's descriptors are operands of their own), and the next run starts with
+  // that tile already on its way (flags bit 0).  Ring-slot parity continues from run to run: `gt` counts the piece's tiles.
+  struct RunP {
+    const T* sk;
+    const T* sv;
+    int ksl_b, vsl_b, slen, seg, t0, n;
+  };
+  auto run_params = [&](int t) -> RunP {
+    RunP r;
+    int seg_tiles;
+    if (p.include_self && t < p.tiles_self) {
+      r.seg = 0; r.t0 = t; seg_tiles = p.tiles_self;
+      r.sk = (const T*)p.k_self + (int64_t)b * p.ks_sb + (int64_t)h * p.ks_sh;
+      r.sv = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
+      r.ksl_b = (int)p.ks_sl * 2; r.vsl_b = (int)p.vs_sl * 2; r.slen = p.Ls;
+    } else {
+      const int rr = t - p.tiles_self;
+      const int n = rr / p.tiles_ref;
+      r.seg = p.include_self + n; r.t0 = rr - n * p.tiles_ref; seg_tiles = p.tiles_ref;
+      r.sk = (const T*)p.k_ref + (int64_t)b * p.kr_sb + (int64_t)n * p.kr_sn + (int64_t)h * p.kr_sh;
+      r.sv = (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)n * p.vr_sn + (int64_t)h * p.vr_sh;
+      r.ksl_b = (int)p.kr_sl * 2; r.vsl_b = (int)p.vr_sl * 2; r.slen = p.Lr;
+    }
+    const int seg_left = seg_tiles - r.t0, piece_left = tile_end - t;
+    r.n = seg_left < piece_left ? seg_left : piece_left;
+    return r;
+  };
+  if (tile_begin < tile_end) {
+    int t = tile_begin, gt = 0;
+    int first = 1, prefetched = 0;
+    RunP cur = run_params(t);
     while (t < tile_end) {
-      int seg, t0, seg_tiles;
-      if (p.include_self && t < p.tiles_self) {
-        seg = 0; t0 = t; seg_tiles = p.tiles_self;
-      } else {
-        const int r = t - p.tiles_self;
-        const int n = r / p.tiles_ref;
-        seg = p.include_self + n; t0 = r - n * p.tiles_ref; seg_tiles = p.tiles_ref;
-      }
-      const int seg_left = seg_tiles - t0, piece_left = tile_end - t;
-      const int n_run = seg_left < piece_left ? seg_left : piece_left;
-      const T* sk;
-      const T* sv;
-      int ksl_b, vsl_b, slen;
-      if (p.include_self && seg == 0) {
-        sk = (const T*)p.k_self + (int64_t)b * p.ks_sb + (int64_t)h * p.ks_sh;
-        sv = (const T*)p.v_self + (int64_t)b * p.vs_sb + (int64_t)h * p.vs_sh;
-        ksl_b = (int)p.ks_sl * 2; vsl_b = (int)p.vs_sl * 2; slen = p.Ls;
-      } else {
-        const int n = seg - p.include_self;
-        sk = (const T*)p.k_ref + (int64_t)b * p.kr_sb + (int64_t)n * p.kr_sn + (int64_t)h * p.kr_sh;
-        sv = (const T*)p.v_ref + (int64_t)b * p.vr_sb + (int64_t)n * p.vr_sn + (int64_t)h * p.vr_sh;
-        ksl_b = (int)p.kr_sl * 2; vsl_b = (int)p.vr_sl * 2; slen = p.Lr;
-      }
-      const i32x4 kd = make_rsrc_words(sk, (unsigned)((slen - 1) * ksl_b + 128));
-      const i32x4 vd = make_rsrc_words(sv, (unsigned)((slen - 1) * vsl_b + 128));
-      const int kstep = KVB * ksl_b, vstep = KVB * vsl_b;
-      const int ksoff = t0 * kstep, vsoff = t0 * vstep;
-      unsigned ko[2], vo[2];
+      const int has_next = (t + cur.n < tile_end) ? 1 : 0;
+      const RunP nx = has_next ? run_params(t + cur.n) : cur;
+      const i32x4 kd = make_rsrc_words(cur.sk, (unsigned)((cur.slen - 1) * cur.ksl_b + 128));
+      const i32x4 vd = make_rsrc_words(cur.sv, (unsigned)((cur.slen - 1) * cur.vsl_b + 128));
+      const i32x4 nkd = make_rsrc_words(nx.sk, (unsigned)((nx.slen - 1) * nx.ksl_b + 128));
+      const i32x4 nvd = make_rsrc_words(nx.sv, (unsigned)((nx.slen - 1) * nx.vsl_b + 128));
+      const int kstep = KVB * cur.ksl_b, vstep = KVB * cur.vsl_b;
+      const int ksoff = (cur.t0 + prefetched) * kstep, vsoff = (cur.t0 + prefetched) * vstep;   // the first tile THIS run fetches
+      const int nksoff = nx.t0 * KVB * nx.ksl_b, nvsoff = nx.t0 * KVB * nx.vsl_b;
+      unsigned ko[2], vo[2], nko[2], nvo[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        ko[c] = (unsigned)(srow[c] * ksl_b + ((pslot ^ ((srow[c] >> 1) & 7)) * 16));
-        vo[c] = (unsigned)(srow[c] * vsl_b + ((pslot ^ (((srow[c] >> 1) & 1) << 2)) * 16));
+        ko[c] = (unsigned)(srow[c] * cur.ksl_b + ((pslot ^ ((srow[c] >> 1) & 7)) * 16));
+        vo[c] = (unsigned)(srow[c] * cur.vsl_b + ((pslot ^ (((srow[c] >> 1) & 1) << 2)) * 16));
+        nko[c] = (unsigned)(srow[c] * nx.ksl_b + ((pslot ^ ((srow[c] >> 1) & 7)) * 16));
+        nvo[c] = (unsigned)(srow[c] * nx.vsl_b + ((pslot ^ (((srow[c] >> 1) & 1) << 2)) * 16));
       }
+      const unsigned par = (unsigned)(gt & 1) << 13;                       // ring slot of this run's first tile
+      const int wbr = wb ^ (int)(((unsigned)((gt ^ prefetched) & 1)) << 13);   // ... of the first tile this run FETCHES
       const int thr = first ? (int)0xBF800000 : (int)0x45000000;   // -1.0: the item's first tile always takes the exact path; 2^11 after
+      const int flags = prefetched | (has_next << 1);
+#define W128_OPERANDS                                                                                                            \
+  [ka0] "v"(ka[0] ^ par), [ka1] "v"(ka[1] ^ par), [ka2] "v"(ka[2] ^ par), [ka3] "v"(ka[3] ^ par), [va0] "v"(va[0] ^ par),        \
+      [va1] "v"(va[1] ^ par), [ko0] "v"(ko[0]), [ko1] "v"(ko[1]), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [nko0] "v"(nko[0]),        \
+      [nko1] "v"(nko[1]), [nvo0] "v"(nvo[0]), [nvo1] "v"(nvo[1]), [kd] "s"(kd), [vd] "s"(vd), [nkd] "s"(nkd), [nvd] "s"(nvd),    \
+      [kstep] "s"(kstep), [vstep] "s"(vstep), [ksoff] "s"(ksoff), [vsoff] "s"(vsoff), [nksoff] "s"(nksoff), [nvsoff] "s"(nvsoff), \
+      [n] "s"(cur.n), [thr] "s"(thr), [wb] "s"(wbr), [flags] "s"(flags)
       if (std::is_same<T, __bf16>::value) {
-        asm volatile(W128_RUN_ASM_BF16
-                     :
-                     : [ka0] "v"(ka[0]), [ka1] "v"(ka[1]), [ka2] "v"(ka[2]), [ka3] "v"(ka[3]), [va0] "v"(va[0]), [va1] "v"(va[1]),
-                       [ko0] "v"(ko[0]), [ko1] "v"(ko[1]), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [kd] "s"(kd), [vd] "s"(vd),
-                       [kstep] "s"(kstep), [vstep] "s"(vstep), [ksoff] "s"(ksoff), [vsoff] "s"(vsoff), [n] "s"(n_run), [thr] "s"(thr),
-                       [wb] "s"(wb)
-                     : W128_RUN_CLOBBERS);
+        asm volatile(W128_RUN_ASM_BF16 : : W128_OPERANDS : W128_RUN_CLOBBERS);
       } else {
-        asm volatile(W128_RUN_ASM_F16
-                     :
-                     : [ka0] "v"(ka[0]), [ka1] "v"(ka[1]), [ka2] "v"(ka[2]), [ka3] "v"(ka[3]), [va0] "v"(va[0]), [va1] "v"(va[1]),
-                       [ko0] "v"(ko[0]), [ko1] "v"(ko[1]), [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [kd] "s"(kd), [vd] "s"(vd),
-                       [kstep] "s"(kstep), [vstep] "s"(vstep), [ksoff] "s"(ksoff), [vsoff] "s"(vsoff), [n] "s"(n_run), [thr] "s"(thr),
-                       [wb] "s"(wb)
-                     : W128_RUN_CLOBBERS);
+        asm volatile(W128_RUN_ASM_F16 : : W128_OPERANDS : W128_RUN_CLOBBERS);
       }
-      first = false;
-      t += n_run;
-      if (FOLD) fold_boundary(seg, t < tile_end);   // a piece that stops inside a segment closes what it has
+#undef W128_OPERANDS
+      first = 0;
+      t += cur.n;
+      gt += cur.n;
+      prefetched = has_next;
+      if (FOLD) fold_boundary(cur.seg, t < tile_end);   // a piece that stops inside a segment closes what it has
+      cur = nx;
     }
   }
 

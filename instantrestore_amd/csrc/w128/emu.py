@@ -165,6 +165,11 @@ class Emu:
             return None
         if op == "cbranch_scc1":
             return sem[1] if w.scc else None
+        if op == "cbranch_scc0":
+            return None if w.scc else sem[1]
+        if op == "sbitcmp1":
+            w.scc = bool((w.s[sem[1]] >> sem[2]) & 1)
+            return None
         if op == "branch":
             return sem[1]
         if op == "smov_op":
@@ -200,10 +205,11 @@ class Emu:
             w.m0 = w.s[G.S_DMA] + sem[1]
             return None
         if op == "dma":
-            _, which, c = sem
-            arr, base = w.ops["kd" if which == "k" else "vd"]
-            voff = w.ops[f"{which}o{c}"].astype(np.int64)
-            soff = w.s[G.S_KSOFF if which == "k" else G.S_VSOFF]
+            _, which, c, nxt = sem
+            pre = "n" if nxt else ""
+            arr, base = w.ops[pre + ("kd" if which == "k" else "vd")]
+            voff = w.ops[f"{pre}{which}o{c}"].astype(np.int64)
+            soff = int(w.ops["nksoff" if which == "k" else "nvsoff"]) if nxt else w.s[G.S_KSOFF if which == "k" else G.S_VSOFF]
             for l in range(64):
                 src = base + int(voff[l]) + soff
                 self.lds[w.m0 + 16 * l:w.m0 + 16 * l + 16] = arr[src:src + 16]

@@ -41,7 +41,7 @@ V_TS0, V_TS1 = 208, 209
 V_T = 210                          # t0 .. t7 : v210 .. v217
 V_KA, V_VA = 218, 222              # private copies of the LDS read addresses: ka[4], va[2]
 V_CLOBBER = (32, 223)
-S_T, S_N, S_KSOFF, S_VSOFF, S_DMA, S_THR, S_TMP, S_TMP2 = 60, 61, 62, 63, 64, 65, 66, 67
+S_T, S_N, S_KSOFF, S_VSOFF, S_DMA, S_THR, S_TMP, S_FLAGS = 60, 61, 62, 63, 64, 65, 66, 67
 S_CLOBBER = (60, 67)
 
 TILE = 8192
@@ -202,19 +202,28 @@ class Gen:
         off = V_OFF + st * 2048 + half * 1024
         self.emit("lds", f"ds_read_b64_tr_b16 {a(dst, 2)}, {v(V_VA + db)} offset:{off}", ("ds_read_tr", ("a", dst), V_VA + db, off))
 
-    def dma_piece(self, which, c):
-        """one 1-KiB LDS-DMA piece of the tile the DMA stream stands at: which = 'k' | 'v', c = 0 | 1 (rows 32 c + 8 wid ...)"""
+    def dma_m0(self, which, c):
         base = (K_OFF if which == "k" else V_OFF) + c * 4096
-        desc = "%[kd]" if which == "k" else "%[vd]"
-        voff = f"%[{which}o{c}]"
-        soff = s(S_KSOFF if which == "k" else S_VSOFF)
         self.salu(f"s_add_u32 m0, {s(S_DMA)}, {base}", ("dma_m0", base))
-        self.nop(0)
-        self.emit("vmem", f"buffer_load_dwordx4 {voff}, {desc}, {soff} offen lds", ("dma", which, c))
 
-    def dma_advance(self):
-        self.salu(f"s_add_u32 {s(S_KSOFF)}, {s(S_KSOFF)}, %[kstep]", ("sadd_op", S_KSOFF, "kstep"))
-        self.salu(f"s_add_u32 {s(S_VSOFF)}, {s(S_VSOFF)}, %[vstep]", ("sadd_op", S_VSOFF, "vstep"))
+    def dma_load(self, which, c, nxt=False):
+        """one 1-KiB LDS-DMA piece of the tile the DMA stream stands at: which = 'k' | 'v', c = 0 | 1 (rows 32 c + 8 wid ...).
+        nxt: the tile is the NEXT run's first one (its descriptors / offsets are separate operands)"""
+        pre = "n" if nxt else ""
+        desc = f"%[{pre}kd]" if which == "k" else f"%[{pre}vd]"
+        voff = f"%[{pre}{which}o{c}]"
+        soff = f"%[nksoff]" if (nxt and which == "k") else f"%[nvsoff]" if nxt else s(S_KSOFF if which == "k" else S_VSOFF)
+        self.emit("vmem", f"buffer_load_dwordx4 {voff}, {desc}, {soff} offen lds", ("dma", which, c, nxt))
+
+    def dma_piece(self, which, c, nxt=False):
+        self.dma_m0(which, c)
+        self.nop(0)                      # M0 written by the scalar ALU -> LDS-DMA reading it: one wait state
+        self.dma_load(which, c, nxt)
+
+    def dma_advance(self, offsets=True):
+        if offsets:
+            self.salu(f"s_add_u32 {s(S_KSOFF)}, {s(S_KSOFF)}, %[kstep]", ("sadd_op", S_KSOFF, "kstep"))
+            self.salu(f"s_add_u32 {s(S_VSOFF)}, {s(S_VSOFF)}, %[vstep]", ("sadd_op", S_VSOFF, "vstep"))
         self.salu(f"s_xor_b32 {s(S_DMA)}, {s(S_DMA)}, {TILE}", ("sxor_imm", S_DMA, TILE))
 
     def toggle_read_slot(self):
@@ -224,12 +233,13 @@ class Gen:
             self.valu(f"v_xor_b32 {v(V_VA + k)}, {TILE}, {v(V_VA + k)}", ("xor_imm", V_VA + k, TILE))
 
     # ---- one phase: MFMAs with the fillers of each gap behind them -----------------------------------------------
-    def phase(self, qk_b, sm_b, pv_b, site, extras=None, tail=None):
-        """qk_b / sm_b / pv_b: block index or None.  extras: dict gap -> list of thunks (after that gap's softmax group).
-        tail: thunks after the check."""
+    def phase(self, qk_b, sm_b, pv_b, site, extras=None, tail=None, pre=None):
+        """qk_b / sm_b / pv_b: block index or None.  extras / pre: dict gap -> list of thunks after / before that gap's softmax
+        group.  tail: thunks after the check."""
         ms = (self.qk_mfmas(qk_b) if qk_b is not None else []) + (self.pv_mfmas(pv_b) if pv_b is not None else [])
         groups = self.sm_groups(sm_b) if sm_b is not None else []
         extras = extras or {}
+        pre = pre or {}
         ngap = max(len(ms), 1)
         # the 16 softmax groups are spread over the gaps that exist (16 MFMAs: one group per gap)
         per_gap = [[] for _ in range(ngap)]
@@ -238,6 +248,8 @@ class Gen:
         for g in range(ngap):
             if g < len(ms):
                 self.mfma(*ms[g][1:])
+            for th in pre.get(g, []):
+                th()
             for th in per_gap[g]:
                 th()
             for th in extras.get(g, []):
@@ -295,7 +307,11 @@ class Gen:
 
     # ---- the run --------------------------------------------------------------------------------------------------
     def run(self):
-        """the stream of one run of n >= 1 tiles (operands: see the asm statement in shared_attn_fwd_w128.hip)"""
+        """the stream of one run of n >= 1 tiles (operands: see the asm statement in shared_attn_fwd_w128.hip).
+        Stream v2: the DMA stream runs ACROSS runs - the last DMA slot of a run fetches the first tile of the next run (its
+        descriptors are separate operands, flags bit 1), and a run whose first tile is already on its way (flags bit 0) starts
+        with its second one; ring-slot parity continues from run to run (the C++ side hands over read addresses and the DMA base
+        for the parity the run starts at)."""
         g = self
         # state in: m, l, l_done from a[192:203]; minus the reference, 16 copies per block
         for k in range(12):
@@ -312,13 +328,17 @@ class Gen:
         g.salu(f"s_mov_b32 {s(S_VSOFF)}, %[vsoff]", ("smov_op", S_VSOFF, "vsoff"))
         g.salu(f"s_mov_b32 {s(S_DMA)}, %[wb]", ("smov_op", S_DMA, "wb"))
         g.salu(f"s_mov_b32 {s(S_THR)}, %[thr]", ("smov_op", S_THR, "thr"))
-        # every wave is done with the ring (the previous run's last fragment reads): tile 0 -> slot 0, tile 1 -> slot 1
-        g.salu("s_waitcnt vmcnt(0) lgkmcnt(0)", ("waitcnt",))
+        g.salu(f"s_mov_b32 {s(S_FLAGS)}, %[flags]", ("smov_op", S_FLAGS, "flags"))
+        # every wave is done with the previous run's fragment reads: the slot beside this run's first tile may be overwritten
+        g.salu("s_waitcnt lgkmcnt(0)", ("waitcnt",))
         g.salu("s_barrier", ("barrier",))
+        g.salu(f"s_bitcmp1_b32 {s(S_FLAGS)}, 0", ("sbitcmp1", S_FLAGS, 0))
+        g.salu("s_cbranch_scc1 PREF_%=", ("cbranch_scc1", "PREF"))
         for which in "kv":
             for c in range(2):
                 g.dma_piece(which, c)
         g.dma_advance()
+        g.label("PREF")
         g.salu(f"s_cmp_lt_u32 {s(S_N)}, 2", ("scmp_ltu_imm", S_N, 2))
         g.salu("s_cbranch_scc1 ONE_%=", ("cbranch_scc1", "ONE"))
         for which in "kv":
@@ -328,6 +348,15 @@ class Gen:
         g.salu("s_waitcnt vmcnt(4)", ("waitcnt",))
         g.salu("s_branch GO_%=", ("branch", "GO"))
         g.label("ONE")
+        g.salu(f"s_bitcmp1_b32 {s(S_FLAGS)}, 1", ("sbitcmp1", S_FLAGS, 1))
+        g.salu("s_cbranch_scc0 ONE0_%=", ("cbranch_scc0", "ONE0"))
+        for which in "kv":
+            for c in range(2):
+                g.dma_piece(which, c, nxt=True)
+        g.dma_advance(offsets=False)
+        g.salu("s_waitcnt vmcnt(4)", ("waitcnt",))
+        g.salu("s_branch GO_%=", ("branch", "GO"))
+        g.label("ONE0")
         g.salu("s_waitcnt vmcnt(0)", ("waitcnt",))
         g.label("GO")
         g.salu("s_barrier", ("barrier",))
@@ -338,6 +367,7 @@ class Gen:
             for db in range(2):
                 for half in range(2):
                     g.v_read(st, db, half)
+        g.toggle_read_slot()                          # the read addresses now stand at tile 1's slot
         g.salu("s_waitcnt lgkmcnt(0)", ("waitcnt",))
         # pipeline fill
         g.phase(0, None, None, None)                  # phase -1
@@ -351,24 +381,39 @@ class Gen:
         g.label("LOOP")
         g.salu("s_waitcnt vmcnt(0) lgkmcnt(0)", ("waitcnt",))      # this wave's pieces of tile t have landed
         g.salu("s_barrier", ("barrier",))                            # ... and everybody's; nobody reads tile t-1's slots any more
-        g.toggle_read_slot()
         # phase 4t-2: QK(t-1, 3), softmax(t-1, 2), PV(t-1, 1); K(t) fragments behind the last use of K(t-1)'s
         kfr = [(kh, ks) for ks in range(4) for kh in range(2)]     # the order the QK^T MFMAs consume them
         ex = {}
         for j, (kh, ks) in enumerate(kfr):
             ex.setdefault(j + 1, []).append(lambda kh=kh, ks=ks: g.k_read(kh, ks))
         g.phase(3, 2, 1, "L2", extras=ex)
-        # phase 4t-1: QK(t, 0), softmax(t-1, 3), PV(t-1, 2); LDS-DMA of tile t+1 (if there is one) in four gaps
+        # phase 4t-1: QK(t, 0), softmax(t-1, 3), PV(t-1, 2); the DMA slot of the tile: tile t+1 of this run, or - behind the run's
+        # last tile - the first tile of the next run, or nothing.  M0 is written ahead of a gap's softmax group and the transfer
+        # issued behind it (the wait state between the two is the group itself)
         g.salu("s_waitcnt lgkmcnt(0)", ("waitcnt",))
+        thr_reset = [lambda: g.salu(f"s_mov_b32 {s(S_THR)}, 0x45000000", ("smov_imm", S_THR, 0x45000000))]
+
+        def dma_slots(nxt):
+            pre, post = {}, {}
+            for gap, (which, c) in zip((2, 5, 9, 12), (("k", 0), ("k", 1), ("v", 0), ("v", 1))):
+                pre[gap] = [lambda which=which, c=c: g.dma_m0(which, c)]
+                post[gap] = [lambda which=which, c=c: g.dma_load(which, c, nxt)]
+            post[13] = [lambda: g.dma_advance(offsets=not nxt)]
+            return pre, post
         g.salu(f"s_add_u32 {s(S_TMP)}, {s(S_T)}, 1", ("sadd_imm", S_TMP, S_T, 1))
-        g.salu(f"s_cmp_ge_u32 {s(S_TMP)}, {s(S_N)}", ("scmp_geu", S_TMP, S_N))
-        g.salu("s_cbranch_scc1 NODMA_%=", ("cbranch_scc1", "NODMA"))
-        ex = {2: [lambda: g.dma_piece("k", 0)], 5: [lambda: g.dma_piece("k", 1)], 9: [lambda: g.dma_piece("v", 0)],
-              12: [lambda: g.dma_piece("v", 1), lambda: g.dma_advance()]}
-        g.phase(0, 3, 2, "L3", extras=ex, tail=[lambda: g.salu(f"s_mov_b32 {s(S_THR)}, 0x45000000", ("smov_imm", S_THR, 0x45000000))])
+        g.salu(f"s_cmp_lt_u32 {s(S_TMP)}, {s(S_N)}", ("scmp_ltu", S_TMP, S_N))
+        g.salu("s_cbranch_scc1 DMACUR_%=", ("cbranch_scc1", "DMACUR"))
+        g.salu(f"s_bitcmp1_b32 {s(S_FLAGS)}, 1", ("sbitcmp1", S_FLAGS, 1))
+        g.salu("s_cbranch_scc1 DMANXT_%=", ("cbranch_scc1", "DMANXT"))
+        g.phase(0, 3, 2, "L3n", tail=thr_reset)
         g.salu("s_branch DMADONE_%=", ("branch", "DMADONE"))
-        g.label("NODMA")
-        g.phase(0, 3, 2, "L3n", tail=[lambda: g.salu(f"s_mov_b32 {s(S_THR)}, 0x45000000", ("smov_imm", S_THR, 0x45000000))])
+        g.label("DMANXT")
+        pre, post = dma_slots(True)
+        g.phase(0, 3, 2, "L3x", extras=post, pre=pre, tail=thr_reset)
+        g.salu("s_branch DMADONE_%=", ("branch", "DMADONE"))
+        g.label("DMACUR")
+        pre, post = dma_slots(False)
+        g.phase(0, 3, 2, "L3", extras=post, pre=pre, tail=thr_reset)
         g.label("DMADONE")
         # phase 4t: QK(t, 1), softmax(t, 0), PV(t-1, 3); V(t) fragments behind the last use of V(t-1)'s (MFMA 8 + f)
         ex = {}
@@ -376,9 +421,14 @@ class Gen:
         for f, (st, db) in enumerate(vfr[:7]):
             ex.setdefault(8 + f + 1, []).extend([lambda st=st, db=db: g.v_read(st, db, 0), lambda st=st, db=db: g.v_read(st, db, 1)])
         g.phase(1, 0, 3, "L0", extras=ex)
-        # phase 4t+1: QK(t, 2), softmax(t, 1), PV(t, 0); the last V fragment behind one more MFMA
+        # phase 4t+1: QK(t, 2), softmax(t, 1), PV(t, 0); the last V fragment behind one more MFMA, then the read addresses move on
+        # to the next tile's slot (one vector instruction per gap)
         ex = {0: [lambda: g.v_read(3, 1, 0), lambda: g.v_read(3, 1, 1)],
-              6: [lambda: g.salu("s_waitcnt lgkmcnt(0)", ("waitcnt",))]}
+              7: [lambda: g.salu("s_waitcnt lgkmcnt(0)", ("waitcnt",))]}
+        for k in range(4):
+            ex[1 + k] = [lambda k=k: g.valu(f"v_xor_b32 {v(V_KA + k)}, {TILE}, {v(V_KA + k)}", ("xor_imm", V_KA + k, TILE))]
+        for k in range(2):
+            ex[5 + k] = [lambda k=k: g.valu(f"v_xor_b32 {v(V_VA + k)}, {TILE}, {v(V_VA + k)}", ("xor_imm", V_VA + k, TILE))]
         g.phase(2, 1, 0, "L1", extras=ex)
         g.salu(f"s_add_u32 {s(S_T)}, {s(S_T)}, 1", ("sadd_imm", S_T, S_T, 1))
         g.salu(f"s_cmp_lt_u32 {s(S_T)}, {s(S_N)}", ("scmp_ltu", S_T, S_N))
@@ -395,7 +445,7 @@ class Gen:
             g.acc_write(A_STATE + k, V_M + k)
         g.salu("s_branch END_%=", ("branch", "END"))
         # ---- rare paths, out of line ----------------------------------------------------------------------------------
-        for site, b in (("P0", 0), ("P1", 1), ("L2", 2), ("L3", 3), ("L3n", 3), ("L0", 0), ("L1", 1), ("D2", 2), ("D3", 3)):
+        for site, b in (("P0", 0), ("P1", 1), ("L2", 2), ("L3", 3), ("L3x", 3), ("L3n", 3), ("L0", 0), ("L1", 1), ("D2", 2), ("D3", 3)):
             g.slow_path(b, site)
         g.label("END")
         return self.out

@@ -190,7 +190,19 @@ def test_mass_through_the_remainder_split_at_the_cfg2_shapes(ops, shape, adain, 
     out, mass = ops.shared_attention(q, k, v, rk, rv, return_mass=True, **kw)
     nosplit = ops.shared_attention(q, k, v, rk, rv, return_mass=True, split=False, **kw)[1]
     second = ops.attn_segment_mass(q, k, rk, lse, heads=H, scale=0.125, include_self=bool(t), q_prescaled=presc)
-    assert torch.equal(out, out0)
+    # the output of a launch that also leaves the masses is the output of the same kernel without them, bit for bit.  Round 6:
+    # where the default dispatch takes the 128-row kernel (pre-scaled Q, L >= 4096) the masses come from the 64-row kernel
+    # (the 128-row kernel has no such form), so "the same kernel" is tuning 13 there and the default output agrees to rounding
+    if "w128" in ops.shared_attention_kernel_name(q, k, v, rk, rv, **kw):
+        prev = ops.set_attn_variant(13)
+        try:
+            out13 = ops.shared_attention(q, k, v, rk, rv, **kw)
+        finally:
+            ops.set_attn_variant(prev)
+        assert torch.equal(out, out13)
+        assert float((out.float() - out0.float()).abs().max()) <= 2 * 2.0 ** -8 * float(out0.float().abs().max()) + 4e-4
+    else:
+        assert torch.equal(out, out0)
     assert float((mass - second).abs().max()) <= 1e-4, float((mass - second).abs().max())
     assert float((nosplit - second).abs().max()) <= 1e-4
     assert float((mass.sum(-1) - 1).abs().max()) <= 1e-5

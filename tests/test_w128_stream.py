@@ -16,36 +16,58 @@ import emu as E   # noqa: E402
 import gen as G   # noqa: E402
 
 
-def _setup_wave(w, dtype, Q, kbytes, vbytes, ksl_b, vsl_b, t0, n, first):
+def _lane_offsets(wid, ksl_b, vsl_b):
+    lane = np.arange(64)
+    tid = 64 * wid + lane
+    pslot = tid & 7
+    out = {}
+    for c in range(2):
+        srow = (tid >> 3) + 32 * c
+        out[f"ko{c}"] = (srow * ksl_b + ((pslot ^ ((srow >> 1) & 7)) * 16)).astype(np.uint32)
+        out[f"vo{c}"] = (srow * vsl_b + ((pslot ^ (((srow >> 1) & 1) << 2)) * 16)).astype(np.uint32)
+    return out
+
+
+def _load_q(w, dtype, Q):
     lane = np.arange(64)
     lq, hi = lane & 31, lane >> 5
-    wid = w.wid
     # Q fragments: block b, k-step ks: lane holds Q[128 wid + 32 b + lq][16 ks + 8 hi .. + 7]
     for b in range(4):
         for ks in range(4):
             for l in range(64):
-                row = 128 * wid + 32 * b + lq[l]
+                row = 128 * w.wid + 32 * b + lq[l]
                 el = E.to16(Q[row, 16 * ks + 8 * hi[l]:16 * ks + 8 * hi[l] + 8], dtype)
                 for j in range(4):
                     w.a[G.A_Q + 16 * b + 4 * ks + j, l] = np.uint32(el[2 * j]) | (np.uint32(el[2 * j + 1]) << 16)
+
+
+def _setup_wave(w, dtype, run, nxt, par, prefetched, first):
+    """operands of one run statement, the way shared_attn_fwd_w128.hip computes them.  run / nxt: dicts with the segment's byte
+    arrays kb / vb, row strides in bytes ksl_b / vsl_b, first tile t0 and tile count n (nxt: the following run or None); par:
+    ring-slot parity of this run's first tile; prefetched: that tile was issued by the previous run"""
+    lane = np.arange(64)
+    lq, hi = lane & 31, lane >> 5
+    wid = w.wid
+    tog = np.uint32(par << 13)
     for ks in range(4):
-        w.ops[f"ka{ks}"] = (lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4)).astype(np.uint32)
+        w.ops[f"ka{ks}"] = (lq * 128 + (((2 * ks + hi) ^ ((lq >> 1) & 7)) << 4)).astype(np.uint32) ^ tog
     m, g = lane & 15, (lane >> 4) & 1
     sw = (m >> 3) & 1
     for db in range(2):
-        w.ops[f"va{db}"] = ((4 * hi + (m >> 2)) * 128 + ((db ^ sw) << 6) + 32 * g + 8 * (m & 3)).astype(np.uint32)
-    tid = 64 * wid + lane
-    pslot = tid & 7
-    for c in range(2):
-        srow = (tid >> 3) + 32 * c
-        w.ops[f"ko{c}"] = (srow * ksl_b + ((pslot ^ ((srow >> 1) & 7)) * 16)).astype(np.uint32)
-        w.ops[f"vo{c}"] = (srow * vsl_b + ((pslot ^ (((srow >> 1) & 1) << 2)) * 16)).astype(np.uint32)
-    w.ops["kd"], w.ops["vd"] = (kbytes, 0), (vbytes, 0)
-    w.ops["kstep"], w.ops["vstep"] = 64 * ksl_b, 64 * vsl_b
-    w.ops["ksoff"], w.ops["vsoff"] = t0 * 64 * ksl_b, t0 * 64 * vsl_b
-    w.ops["n"] = n
+        w.ops[f"va{db}"] = ((4 * hi + (m >> 2)) * 128 + ((db ^ sw) << 6) + 32 * g + 8 * (m & 3)).astype(np.uint32) ^ tog
+    w.ops.update(_lane_offsets(wid, run["ksl_b"], run["vsl_b"]))
+    w.ops["kd"], w.ops["vd"] = (run["kb"], 0), (run["vb"], 0)
+    w.ops["kstep"], w.ops["vstep"] = 64 * run["ksl_b"], 64 * run["vsl_b"]
+    w.ops["ksoff"], w.ops["vsoff"] = (run["t0"] + prefetched) * 64 * run["ksl_b"], (run["t0"] + prefetched) * 64 * run["vsl_b"]
+    w.ops["n"] = run["n"]
     w.ops["thr"] = int(np.array([-1.0 if first else 2048.0], dtype=np.float32).view(np.uint32)[0])
-    w.ops["wb"] = 1024 * wid
+    w.ops["wb"] = (1024 * wid) ^ ((par ^ prefetched) << 13)
+    w.ops["flags"] = prefetched | (2 if nxt is not None else 0)
+    if nxt is not None:
+        for k_, v_ in _lane_offsets(wid, nxt["ksl_b"], nxt["vsl_b"]).items():
+            w.ops["n" + k_] = v_
+        w.ops["nkd"], w.ops["nvd"] = (nxt["kb"], 0), (nxt["vb"], 0)
+        w.ops["nksoff"], w.ops["nvsoff"] = nxt["t0"] * 64 * nxt["ksl_b"], nxt["t0"] * 64 * nxt["vsl_b"]
 
 
 def _result(waves):
@@ -89,13 +111,16 @@ def _reference(Q, K, V, dtype):
 @pytest.mark.parametrize("dtype", ["bf16", "f16"])
 @pytest.mark.parametrize("runs", [[1], [2], [3], [1, 1], [2, 3], [4, 1, 2]], ids=lambda r: "x".join(map(str, r)))
 @pytest.mark.parametrize("order", ["up", "down"])
-def test_generated_stream_matches_softmax(dtype, runs, order):
+@pytest.mark.parametrize("prefetch", [True, False], ids=["chained", "standalone"])
+def test_generated_stream_matches_softmax(dtype, runs, order, prefetch):
     rng = np.random.default_rng(1000 + sum(runs) * 7 + len(runs))
     ins = G.Gen(dtype).run()
     em = E.Emu(ins, dtype)
     Q = (rng.standard_normal((512, 64)) * 1.3).astype(np.float32)
     waves = [E.Wave(wid, dtype) for wid in range(4)]
-    Ks, Vs = [], []
+    for w in waves:
+        _load_q(w, dtype, Q)
+    Ks, Vs, descs = [], [], []
     for r, n in enumerate(runs):
         stride = 64 if r % 2 == 0 else 192        # the self segment is a view into a fused (L, 3C) projection, references are dense
         # a later run with much larger keys: its first tile outgrows the reference by far (the rare path away from the first tile)
@@ -103,9 +128,14 @@ def test_generated_stream_matches_softmax(dtype, runs, order):
         t0 = 1 if r % 2 else 0                                # a run that starts inside its segment (a K/V-range piece)
         Ks.append(K[64 * t0:64 * (t0 + n)])
         Vs.append(V[64 * t0:64 * (t0 + n)])
+        descs.append(dict(kb=kb, vb=vb, ksl_b=2 * stride, vsl_b=2 * stride, t0=t0, n=n))
+    gt = 0
+    for r, d in enumerate(descs):
+        nxt = descs[r + 1] if (prefetch and r + 1 < len(descs)) else None
         for w in waves:
-            _setup_wave(w, dtype, Q, kb, vb, 2 * stride, 2 * stride, t0, n, first=(r == 0))
+            _setup_wave(w, dtype, d, nxt, par=gt & 1, prefetched=int(prefetch and r > 0), first=(r == 0))
         em.run(waves, order=range(4) if order == "up" else range(3, -1, -1))
+        gt += d["n"]
     O, M, L = _result(waves)
     ref, lse = _reference(Q, np.concatenate(Ks), np.concatenate(Vs), dtype)
     assert all(w.n_mfma == 64 * sum(runs) for w in waves), [w.n_mfma for w in waves]
@@ -134,7 +164,8 @@ def test_rare_path_fires_inside_the_steady_state_loop():
         Kb[:] = E.to16(K, dtype)
         K = E.from16(Kb, dtype)
         for w in waves:
-            _setup_wave(w, dtype, Q, Kb.view(np.uint8).reshape(-1), vb, 128, 128, 0, n, first=True)
+            _load_q(w, dtype, Q)
+            _setup_wave(w, dtype, dict(kb=Kb.view(np.uint8).reshape(-1), vb=vb, ksl_b=128, vsl_b=128, t0=0, n=n), None, par=0, prefetched=0, first=True)
         em.run(waves)
         O, M, L = _result(waves)
         ref, lse = _reference(Q, K, V, dtype)

@@ -598,27 +598,25 @@ def power_probe(step_fn, seconds=3.0):
 
 
 class CapturedStep:
-    """the whole two-stream step captured once in ONE hipGraph (fork / join through the processors' events); ``replay()``
-    re-runs it, ``outs`` / ``keys`` / ``vals`` are the graph's static result tensors"""
+    """the whole two-stream step captured once in ONE hipGraph (fork / join through the processors' events) with the product's
+    own helper, ``kv_harvest.capture_step``; ``replay()`` re-runs it, ``outs`` / ``keys`` / ``vals`` are the graph's static
+    result tensors"""
 
     def __init__(self, layers, B, N, two_streams=True):
-        self.graph = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
+        from instantrestore_amd.kv_harvest import capture_step
         saved = dict(_REF_STREAM)
-        with torch.cuda.stream(s):
-            _REF_STREAM.clear()
-            hot_path_step(layers, B, N, False, two_streams)     # side stream + per-stream workspaces exist before the capture
+        _REF_STREAM.clear()       # the side stream (and the per-stream workspaces) are created by the helper's eager warm-up run
+        try:
+            self._cap = capture_step(lambda: hot_path_step(layers, B, N, False, two_streams, return_kv=True), warmup=1)
+        finally:
             torch.cuda.synchronize()
-            with torch.cuda.graph(self.graph, stream=s):
-                self.outs, self.keys, self.vals = hot_path_step(layers, B, N, False, two_streams, return_kv=True)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        _REF_STREAM.clear()
-        _REF_STREAM.update(saved)
+            _REF_STREAM.clear()
+            _REF_STREAM.update(saved)
+        self.graph = self._cap.graph
+        self.outs, self.keys, self.vals = self._cap.result
 
     def replay(self):
-        self.graph.replay()
+        self._cap.replay()
 
 
 def _first_difference(t, b):
@@ -702,6 +700,33 @@ def extra_graph(layers, B, N, steps):
         detail.update({"mismatching": bad,
                        "eager_repeats_itself": all(torch.equal(a, b) for a, b in zip([t for part in again for t in part], ref))})
     return sec, not bad, detail
+
+
+def extra_cfg1gpu(dev, steps, act_fp32):
+    """configs[0]'s shape on the GPU - ONE identity, 4 references, 512 px, fp16 autocast: the schedule inference/test.py:79-111
+    actually runs (eager, B = 1) - next to the same step replayed from one hipGraph (kv_harvest.capture_step) and the dominant
+    kernel's roofline fraction at B = 1 (40 work items of 512 rows on 256 CUs: every item cut into K/V-range pieces)."""
+    saved = _AUTOCAST["dtype"]
+    layers, (B, N, px, dtype, use_adain) = build_workload("cfg1gpu", True, dev, seed=4321, act_fp32=act_fp32)
+    _AUTOCAST["dtype"] = dtype if act_fp32 else None
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                hot_path_step(layers, B, N, False, False)
+            sec_e = _time_steps(lambda: hot_path_step(layers, B, N, False, False), steps)
+            cap = CapturedStep(layers, B, N, True)
+            for _ in range(3):
+                cap.replay()
+            sec_g = _time_steps(cap.replay, steps)
+            roof = measure_roofline(layers, B, N, True, use_adain, dtype)
+    finally:
+        _AUTOCAST["dtype"] = saved
+    return {"workload": "cfg1gpu: 1 identity, %d refs, %d px, %s" % (N, px, {torch.bfloat16: "bf16", torch.float16: "f16"}[dtype]),
+            "hip_graph": {"images_per_s": round(B / sec_g, 2), "ms_per_step": round(sec_g * 1e3, 4)},
+            "eager_one_stream": {"images_per_s": round(B / sec_e, 2), "ms_per_step": round(sec_e * 1e3, 4),
+                                 "note": "the reference's own schedule; host-bound (issue time of ~80 launches), NOTES 11.11"},
+            "dominant_kernel": {"kernel": roof["kernel"], "ms_per_launch": roof["ms_per_launch"], "achieved": roof["achieved"],
+                                "frac": roof["frac"], "unit": "TFLOP/s", "timing": "20 back-to-back launches (HIP events)"}}
 
 
 def extra_ragged_valid(layers, B, N, keys, vals, cst, sec_all_valid, train_input, steps, dev):
@@ -1010,7 +1035,11 @@ def control_plane_only(args):
     if world > 1:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per_rank_ms = [float(t.item()) * 1e3 / args.steps]
     if world > 1:
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)                       # every rank's own time, as the GPU path reports them
+        per_rank_ms = [float(g.item()) * 1e3 / args.steps for g in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     # small images: control flow, not a measurement (one rank: the leg's HIP image kernels would need the GPU)
     sg = extra_scatter_gather(B, N, 64, world, rank, torch.device("cpu"), backend) if world > 1 else {"skipped": "one rank"}
@@ -1023,6 +1052,7 @@ def control_plane_only(args):
                           "config": {"workload": args.config, "identities_per_gpu": B, "global_batch": B * world,
                                      "parallelism": "dp%d (independent identities)" % world,
                                      "rccl_ranks": (dist.get_world_size() if world > 1 else 1),
+                                     "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
                                      "scatter_gather_ms": sg.get("scatter_gather_ms"), "extras": {"scatter_gather": sg}}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -1078,7 +1108,11 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+            # RCCL over xGMI.  A communicator that does not come up must not hang the node for torch's default ten minutes:
+            # the bring-up (and every collective after it) gives up after IR_BENCH_RCCL_TIMEOUT seconds and the run fails loudly
+            import datetime
+            dist.init_process_group(backend="nccl", device_id=dev,
+                                    timeout=datetime.timedelta(seconds=float(os.environ.get("IR_BENCH_RCCL_TIMEOUT", "300"))))
         else:
             dist.init_process_group(backend=backend)
     elif os.environ.get("IR_BENCH_FORCE_DIST", "1") == "1" and backend == "nccl":
@@ -1151,7 +1185,11 @@ def main():
         in_step_ms = [a.elapsed_time(b) for a, b in in_step]
     assert all(torch.isfinite(o).all() for o in outs)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if use_dist:
+        gathered = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, t)            # every rank's own time for its K steps (the line reports them beside the MAX)
+        per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -1254,6 +1292,11 @@ def main():
                     extras["probs_dump"] = extra_probs_dump(layers, B, N, train_input, dtype, dev)
                 except Exception as e:
                     extras["probs_dump"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                if args.config == "cfg2":
+                    try:
+                        extras["cfg1gpu"] = extra_cfg1gpu(dev, max(10, args.steps), act_fp32)
+                    except Exception as e:
+                        extras["cfg1gpu"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 if args.config != "cfg5":
                     try:
                         extras["e2e_topology_host"] = extra_e2e(B, N, px, dtype, max(2, args.steps // 2), dev)
@@ -1326,6 +1369,7 @@ def main():
                                     "is out of scope), so a replayed graph / two streams may overlap ANY of them; in the real UNet layer i+1 waits for "
                                     "layer i of its own UNet and only the two UNets overlap (the one-stream figure under extras is the no-overlap bound)",
                 "rccl_ranks": (dist.get_world_size() if use_dist else 1),
+                "per_rank_ms_per_step": [round(x, 4) for x in per_rank_ms],
                 "rccl_communicator": ("real (%d ranks)" % dist.get_world_size()) if use_dist else "none: %s" % ((single_rank_comm or {}).get("error") or "IR_BENCH_FORCE_DIST=0"),
                 "scatter_gather_ms": None if not extras else extras.get("scatter_gather", {}).get("scatter_gather_ms"),
                 "extras": extras,

@@ -173,3 +173,67 @@ def get_conditioning_keys_values(original_unet, model_input: torch.Tensor, times
     finally:
         for p, flag in zip(procs, saved_stats):
             p.capture_stats = flag
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# round 6: the step as ONE hipGraph (inference/test.py:79-111 runs eagerly with B = 1: ~80 small launches whose issue time
+# on the host exceeds their run time on the device - NOTES 11.11)
+# ------------------------------------------------------------------------------------------------------------------------
+class CapturedStep:
+    """``fn()`` - both UNets' attention path: reference capture -> harvest -> main UNet - recorded once into ONE hipGraph.
+
+    ``fn`` takes no arguments: it reads STATIC input tensors the caller owns (refill them with ``copy_`` before a replay) and
+    returns tensors (or nested lists / tuples of tensors), which become the graph's static results: ``result`` after every
+    ``replay()``.  Streams forked inside ``fn`` (the two-stream schedule of :func:`enable_stream_overlap`) are captured with
+    it as long as they are joined back through events before ``fn`` returns, which the processors' ``ref_events`` do.
+
+    Capture rules the helper takes care of: ``fn`` runs ``warmup`` times eagerly on the capture stream first (lazy
+    initialisation - scratch buffers, folded weights, kernel attributes - must not happen inside the capture; the scratch
+    buffers handed out during the capture are pinned for the life of the thread, ``ops._workspace``), and the capture stream
+    is not the default stream.  Shapes are frozen: one ``CapturedStep`` per (B, N, px) - :class:`StepGraphs` keeps them."""
+
+    def __init__(self, fn, warmup: int = 1, stream: "torch.cuda.Stream | None" = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("capture_step needs the GPU (the product has no CPU path)")
+        self.graph = torch.cuda.CUDAGraph()
+        self.stream = stream if stream is not None else torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            for _ in range(max(1, int(warmup))):
+                fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.result = fn()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.replays = 0
+
+    def replay(self):
+        """launch the recorded step on the current stream; returns the static results (valid once the stream reaches them)"""
+        self.graph.replay()
+        self.replays += 1
+        return self.result
+
+
+def capture_step(fn, warmup: int = 1, stream=None) -> CapturedStep:
+    """record ``fn()`` into one hipGraph (see :class:`CapturedStep`)"""
+    return CapturedStep(fn, warmup=warmup, stream=stream)
+
+
+class StepGraphs:
+    """one captured step per shape key, e.g. ``(B, N, px, dtype)``: ``graphs.run(key, make_fn)`` captures on first use -
+    ``make_fn()`` returns the zero-argument step closed over that shape's static inputs - and replays afterwards"""
+
+    def __init__(self, max_entries: int = 8):
+        self._g = {}
+        self.max_entries = max_entries
+
+    def run(self, key, make_fn, warmup: int = 1):
+        g = self._g.get(key)
+        if g is None:
+            if len(self._g) >= self.max_entries:          # oldest capture first (dict order); its graph and static tensors go
+                self._g.pop(next(iter(self._g)))
+            g = self._g[key] = capture_step(make_fn(), warmup=warmup)
+        return g.replay()
+
+    def __len__(self):
+        return len(self._g)

@@ -29,6 +29,8 @@ def test_bench_gpus_2_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["global_batch"] == 16
     assert d["config"]["parallelism"].startswith("dp2") and d["scaling"] == "weak"
     assert d["max_over_ranks_s"] >= 0.02                       # rank 1 "stepped" for 20 ms: the MAX, not rank 0's 10 ms
+    per = d["config"]["per_rank_ms_per_step"]                 # round 6: every rank's own time beside the MAX (2 steps each)
+    assert len(per) == 2 and 4.5 <= per[0] < per[1] and per[1] >= 9.5 and abs(max(per) * 2e-3 - d["max_over_ranks_s"]) < 2e-3
     sg = d["config"]["extras"]["scatter_gather"]
     assert sg["ok"] and sg["rccl_ranks"] == 2 and sg["backend"] == "gloo" and d["config"]["scatter_gather_ms"] == sg["scatter_gather_ms"]
 

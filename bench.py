@@ -211,10 +211,10 @@ def measure_roofline(layers, B, N, train_input, use_adain, dtype):
         "traffic": _pmc_traffic_bytes() if (B, N, L, H, train_input, use_adain) == (8, 4, 4096, 5, True, True) else None,
         "traffic_static": True,      # read from the committed PMC pass named below, NOT measured in this run (counters need rocprofv3)
         "traffic_unit": "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, %s)" % _pmc_profile_name(),
-        "power_note": "this kernel runs at the 1400 W board cap on random data (profiles/r4_energy_attn.txt): 1.10 J per launch = "
-                      "1.28 pJ/flop at 1386 W and 2.10 GHz against the 2.4 GHz the peak assumes; 0.65 J on all-zero inputs at full clock, the "
-                      "same 1.66 M cycles; an MFMA-only stream of the same instruction holds 1.96 PFLOP/s on random operands under that "
-                      "cap (profiles/r1_ubench_mfma_power.txt, r4_ubench_mfma_reuse.txt)",
+        "power_note": "this kernel runs at the 1400 W board cap on random data: round 6's 128-row kernel needs 1.39 M cycles per launch "
+                      "(the 64-row kernel 1.77 M) and is clocked at 1.96 GHz (2.24 GHz) against the 2.4 GHz the peak assumes - 0.99 J per "
+                      "launch (1.10 J) - profiles/r6_pmc_w128.txt, r6_w128_ab.txt; an MFMA-only stream of the same instruction holds "
+                      "1.92-1.97 PFLOP/s on random operands under that cap (at_power_cap below, measured in this run)",
     }
 
 
@@ -335,7 +335,7 @@ def kernel_class_breakdown(layers, B, N, steps):
 
 
 def _pmc_profile_name():
-    for name in ("r5_pmc_shared_attn.txt", "r4_pmc_shared_attn.txt", "r3_pmc_shared_attn.txt", "r2_pmc_shared_attn.txt", "r1_pmc_shared_attn.txt"):
+    for name in ("r6_pmc_shared_attn.txt", "r5_pmc_shared_attn.txt", "r4_pmc_shared_attn.txt", "r3_pmc_shared_attn.txt", "r2_pmc_shared_attn.txt", "r1_pmc_shared_attn.txt"):
         if os.path.exists(os.path.join(REPO, "profiles", name)):
             return "profiles/" + name
     return "no committed PMC profile"

@@ -16,6 +16,28 @@ def timeit(fn, iters=20, reps=5):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get("GRAPH") == "1":      # round 6: the launches replayed from one hipGraph - device time of small GEMMs without
+        g_ = torch.cuda.CUDAGraph()         # the ~12-us eager launch cadence on top (what a captured B = 1 step sees)
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            fn()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g_, stream=s_):
+                for _ in range(iters):
+                    fn()
+        torch.cuda.current_stream().wait_stream(s_)
+        g_.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g_.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / iters)
+        return sorted(ts)[len(ts) // 2] * 1e3
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -40,6 +62,12 @@ if len(sys.argv) > 1 and sys.argv[1] == "small":
     shapes = [(M, N, K, b) for K in (1024, 1280) for M in (77, 616, 1024) for (N, b) in ((1280, False), (3840, False), (1280, True))
               if not (K == 1024 and N == 3840)]
     shapes += [(512, 3840, 1280, False), (512, 1280, 1280, True), (256, 960, 320, False), (4096, 960, 320, False), (64, 3840, 1280, False)]
+if len(sys.argv) > 1 and sys.argv[1] == "b1":
+    # round 6: ONE identity with 4 references (cfg1gpu): capture layers M = 4 L, shared layers M = L
+    shapes = []
+    for (L, C) in ((256, 1280), (1024, 640), (4096, 320)):
+        for sets in (4, 1):
+            shapes += [(sets * L, 3 * C, C, False), (sets * L, C, C, True)]
 dt = torch.bfloat16
 g = torch.Generator().manual_seed(1)
 tot_v = tot_o = 0.0

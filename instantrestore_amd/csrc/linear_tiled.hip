@@ -660,7 +660,9 @@ hipError_t launch_x(const LinearKParams& p, int cfg, hipStream_t s) {
 int ir_linear_tiled_pick(int64_t M, int N, int K) {
   auto tiles = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (int64_t)((N + bn - 1) / bn); };
   if (tiles(256, 256) >= 160) return IR_LIN_TILE_256x256;
-  if (N % 128 == 0 && tiles(128, 128) >= 128 && tiles(128, 128) <= 192 && K >= 1024 && ((K >> 6) & 1) == 0) return IR_LIN_TILE_128x128_K2;
+  // (round 6: up to ONE round of 256 tiles instead of 192 - M = 1024 x N = 3840 x K = 1280, the capture q/k/v GEMM of one identity with
+  //  four references: 15.0 / 21.6 us against 17.2 / 24.8 us of the plain 128 x 128 tile under graph replay, profiles/r6_gemm_probe_b1_graph.txt)
+  if (N % 128 == 0 && tiles(128, 128) >= 128 && tiles(128, 128) <= 256 && K >= 1024 && ((K >> 6) & 1) == 0) return IR_LIN_TILE_128x128_K2;
   if (N % 128 == 0) return tiles(128, 128) >= 128 ? IR_LIN_TILE_128x128 : IR_LIN_TILE_64x128;
   return tiles(256, 64) >= 512 ? IR_LIN_TILE_256x64 : IR_LIN_TILE_128x64;
 }

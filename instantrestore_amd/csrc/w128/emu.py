@@ -118,6 +118,10 @@ class Emu:
                 r = {"add": x + y, "sub": x - y, "mul": x * y, "max": np.fmax(x, y)}[op]
             w.v[sem[1]] = r.astype(F32).view(U32)
             return None
+        if op == "pk_add":
+            for k in range(2):
+                w.v[sem[1] + k] = (w.vf(sem[2] + k) + w.vf(sem[3] + k)).astype(F32).view(U32)
+            return None
         if op == "max_imm0":
             w.v[sem[1]] = np.fmax(w.vf(sem[2]), F32(0)).view(U32)
             return None

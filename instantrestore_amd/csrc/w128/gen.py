@@ -25,7 +25,10 @@ The instruction list is built as objects (`I`), rendered to inline-asm text for 
 emu.py (tests/test_w128_stream.py), which is how the operand wiring, the pipeline prologue / epilogue, the slot toggling and
 the rare paths are checked without a GPU.
 """
+import os
 import sys
+
+PK_SUM = os.environ.get("W128_PK_SUM") == "1"   # experiment: row sums as one v_pk_add_f32 per pair instead of two v_add_f32
 
 # ---------------------------------------------------------------------------------------------------------------------
 # register map
@@ -179,8 +182,19 @@ class Gen:
                 grp = [lambda e0=e0, x0=x0: self.exp(e0, x0), lambda e1=e1, x1=x1: self.exp(e1, x1)]
                 if g == 1:
                     grp.append(lambda: self.cvt(Pb, V_TS0, V_TS1))      # group 0's pair, before the adds below change the sums
-                grp += [lambda e0=e0: self.add(V_TS0, V_TS0, e0), lambda e1=e1: self.add(V_TS1, V_TS1, e1),
-                        lambda g=g, e0=e0, e1=e1: self.cvt(Pb + g, e0, e1)]
+                if PK_SUM:
+                    # the packed add (and the conversion) of a pair trail its exponentials by one group: a transcendental's result
+                    # is not forwarded to the next vector instruction, and the pair's registers stay intact until the group after
+                    if g >= 2:
+                        p0, p1 = V_E[2 * ((g - 1) & 1)], V_E[2 * ((g - 1) & 1) + 1]
+                        grp += [lambda p0=p0: self.valu(f"v_pk_add_f32 {v(V_TS0, 2)}, {v(V_TS0, 2)}, {v(p0, 2)}", ("pk_add", V_TS0, V_TS0, p0)),
+                                lambda g=g, p0=p0, p1=p1: self.cvt(Pb + g - 1, p0, p1)]
+                    if g == 15:
+                        grp += [lambda e0=e0: self.valu(f"v_pk_add_f32 {v(V_TS0, 2)}, {v(V_TS0, 2)}, {v(e0, 2)}", ("pk_add", V_TS0, V_TS0, e0)),
+                                lambda e0=e0, e1=e1: self.cvt(Pb + 15, e0, e1)]
+                else:
+                    grp += [lambda e0=e0: self.add(V_TS0, V_TS0, e0), lambda e1=e1: self.add(V_TS1, V_TS1, e1),
+                            lambda g=g, e0=e0, e1=e1: self.cvt(Pb + g, e0, e1)]
             groups.append(grp)
         return groups
 
@@ -465,6 +479,8 @@ def reads_writes(ins):
         W.add(sem[1]); R.add(sem[2])
     elif op in ("add", "sub", "mul", "max", "cvt"):
         W.add(sem[1]); R.update(sem[2:4])
+    elif op == "pk_add":
+        W.update((sem[1], sem[1] + 1)); R.update((sem[2], sem[2] + 1, sem[3], sem[3] + 1))
     elif op == "max3":
         W.add(sem[1]); R.update(sem[2:5])
     elif op == "xor_imm":

@@ -22,6 +22,9 @@ CASES = [
     ("cfg2", 8, 4, 4096, 5, torch.bfloat16), ("cfg2", 8, 4, 1024, 10, torch.bfloat16), ("cfg2", 8, 4, 256, 20, torch.bfloat16),
     ("cfg4", 8, 8, 4096, 5, torch.bfloat16), ("cfg4", 8, 8, 256, 20, torch.bfloat16),
     ("cfg5", 16, 4, 16384, 5, torch.float16), ("cfg5", 16, 4, 1024, 20, torch.float16),
+    # round 6: ONE identity under fp16 (configs[0]'s shape on the GPU, the reference's own schedule: inference/test.py:79-111) - the
+    # grids that do not fill the chip: 40 / 20 / 20 work items, every item of the top class cut into K/V-range pieces
+    ("cfg1gpu", 1, 4, 4096, 5, torch.float16), ("cfg1gpu", 1, 4, 1024, 10, torch.float16), ("cfg1gpu", 1, 4, 256, 20, torch.float16),
 ]
 
 

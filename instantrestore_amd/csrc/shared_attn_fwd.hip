@@ -452,7 +452,16 @@ bool ir_attn_default_is_w128(const AttnKParams& p) {
   static const int env = [] { const char* e = getenv("IR_ATTN_W128"); return e == nullptr ? -1 : (e[0] == '0' ? 0 : 1); }();
   if (env == 0) return false;
   if (!ir_attn_w128_supports(p)) return false;
-  return env == 1 ? p.Lq >= 1024 : (IR_W128_DEFAULT != 0 && ir_attn_default_is_w64(p));
+  if (env == 1) return p.Lq >= 1024;
+  if (IR_W128_DEFAULT == 0) return false;
+  if (ir_attn_default_is_w64(p)) return true;
+  // 32x32-token class (1024 <= Lq < 4096; cfg 4's and cfg 5's shapes - at cfg 2's own the two kernels measure equal and the 32-row
+  // kernel stays): the 512-row work items pay off once the K/V walk is long or the item grid is several rounds deep
+  // (profiles/r6_layer_classes.txt: cfg 5 shared +22 %, cfg 4 shared +10 %, capture forms of 1280+ items +3...5 %; 640 items of
+  // 16 tiles -10 %)
+  if (p.Lq < 1024) return false;
+  const long items512 = (long)p.B * p.H * ((p.Lq + 511) / 512);
+  return p.ntiles >= 64 ? (items512 >= 512 || p.ntiles >= 128) : items512 >= 1280;
 }
 
 // ABI v9 (seg_mass): the forward kernels left, per row, the cumulative log-sum-exp c_0 <= c_1 <= ... <= c_{S-1} (= the row's LSE)

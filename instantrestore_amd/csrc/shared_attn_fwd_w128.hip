@@ -83,27 +83,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1,
   const int tile_end = (int)(((long)p.ntiles * (piece + 1)) / npiece);
   const int NTILES = tile_end - tile_begin;
 
-  // ---- state: O = 0, m = l = l_done = 0; Q fragments of the four row blocks into a[128:191] ---------------------------------
-  static_for<128>([&](auto i) { acc_set<A_O + decltype(i)::value>(0.f); });
-  static_for<12>([&](auto i) { acc_set<A_M + decltype(i)::value>(0.f); });
-  const int qrow0 = qb * QB + wid * 128 + lq;
-  {
-    const T* base = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh + hi * 8;
-    static_for<4>([&](auto blk) {
-      constexpr int B_ = decltype(blk)::value;
-      const int row = qrow0 + 32 * B_;
-      const int rc = row < p.Lq ? row : p.Lq - 1;
-      static_for<4>([&](auto ks) {
-        constexpr int KS = decltype(ks)::value;
-        const u32x4 w = *(const u32x4*)(base + (int64_t)rc * p.q_sl + KS * 16);
-        acc_set_u<A_Q + 16 * B_ + 4 * KS + 0>(w[0]);
-        acc_set_u<A_Q + 16 * B_ + 4 * KS + 1>(w[1]);
-        acc_set_u<A_Q + 16 * B_ + 4 * KS + 2>(w[2]);
-        acc_set_u<A_Q + 16 * B_ + 4 * KS + 3>(w[3]);
-      });
-    });
-  }
-
   // ---- lane constants of the run statement -----------------------------------------------------------------------------------
   const unsigned lds0 = (unsigned)(unsigned long long)(IR_LDS unsigned char*)smem;
   if (lds0 & 0x3fffu) __builtin_trap();   // the stream toggles ring slots with XOR 8192: the ring must sit on a 16-KiB boundary (it is the only LDS object: 0)
@@ -194,9 +173,50 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1,
     r.n = seg_left < piece_left ? seg_left : piece_left;
     return r;
   };
+  // The item's FIRST tile goes on its way before anything else (its descriptors need nothing but the work decode), so that its
+  // latency overlaps the Q loads and the accumulator initialisation below; the first run then starts with flags bit 0 set.
+  if (tile_begin < tile_end) {
+    const RunP r0 = run_params(tile_begin);
+    const i32x4 kd0 = make_rsrc_words(r0.sk, (unsigned)((r0.slen - 1) * r0.ksl_b + 128));
+    const i32x4 vd0 = make_rsrc_words(r0.sv, (unsigned)((r0.slen - 1) * r0.vsl_b + 128));
+    const int ksoff0 = r0.t0 * KVB * r0.ksl_b, vsoff0 = r0.t0 * KVB * r0.vsl_b;
+    unsigned ko0[2], vo0[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      ko0[c] = (unsigned)(srow[c] * r0.ksl_b + ((pslot ^ ((srow[c] >> 1) & 7)) * 16));
+      vo0[c] = (unsigned)(srow[c] * r0.vsl_b + ((pslot ^ (((srow[c] >> 1) & 1) << 2)) * 16));
+    }
+    asm volatile("s_nop 4\n\t" W128_DMA0_ASM
+                 :
+                 : [ko0] "v"(ko0[0]), [ko1] "v"(ko0[1]), [vo0] "v"(vo0[0]), [vo1] "v"(vo0[1]), [kd] "s"(kd0), [vd] "s"(vd0),
+                   [ksoff] "s"(ksoff0), [vsoff] "s"(vsoff0), [wb] "s"(wb)
+                 : "memory");
+  }
+
+  // ---- state: O = 0, m = l = l_done = 0; Q fragments of the four row blocks into a[128:191] ---------------------------------
+  static_for<128>([&](auto i) { acc_set<A_O + decltype(i)::value>(0.f); });
+  static_for<12>([&](auto i) { acc_set<A_M + decltype(i)::value>(0.f); });
+  const int qrow0 = qb * QB + wid * 128 + lq;
+  {
+    const T* base = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh + hi * 8;
+    static_for<4>([&](auto blk) {
+      constexpr int B_ = decltype(blk)::value;
+      const int row = qrow0 + 32 * B_;
+      const int rc = row < p.Lq ? row : p.Lq - 1;
+      static_for<4>([&](auto ks) {
+        constexpr int KS = decltype(ks)::value;
+        const u32x4 w = *(const u32x4*)(base + (int64_t)rc * p.q_sl + KS * 16);
+        acc_set_u<A_Q + 16 * B_ + 4 * KS + 0>(w[0]);
+        acc_set_u<A_Q + 16 * B_ + 4 * KS + 1>(w[1]);
+        acc_set_u<A_Q + 16 * B_ + 4 * KS + 2>(w[2]);
+        acc_set_u<A_Q + 16 * B_ + 4 * KS + 3>(w[3]);
+      });
+    });
+  }
+
   if (tile_begin < tile_end) {
     int t = tile_begin, gt = 0;
-    int first = 1, prefetched = 0;
+    int first = 1, prefetched = 1;   // the first tile was issued above
     RunP cur = run_params(t);
     while (t < tile_end) {
       const int has_next = (t + cur.n < tile_end) ? 1 : 0;

@@ -465,6 +465,20 @@ class Gen:
         return self.out
 
 
+def first_tile_dma(dtype="bf16"):
+    """the four LDS-DMA pieces of an item's FIRST tile (ring slot 0), issued by the kernel's prologue before it loads the Q
+    fragments so that the two latencies overlap; the first run then starts with flags bit 0 set.  Operands: ko0 ko1 vo0 vo1 (v),
+    kd vd (s[4]), ksoff vsoff wb (s)."""
+    g = Gen(dtype)
+    for which in "kv":
+        for c in range(2):
+            base = (K_OFF if which == "k" else V_OFF) + c * 4096
+            g.salu(f"s_add_u32 m0, %[wb], {base}", ("dma0_m0", base))
+            g.nop(0)
+            g.emit("vmem", f"buffer_load_dwordx4 %[{which}o{c}], %[{which}d], %[{which}soff] offen lds", ("dma0", which, c))
+    return g.out
+
+
 def reads_writes(ins):
     """(VGPR reads, VGPR writes, AGPR reads, AGPR writes) of one instruction as sets of register indices"""
     sem, op = ins.sem, ins.sem[0]
@@ -570,6 +584,10 @@ def write_inc(path):
             for line in render(ins):
                 f.write('  "' + line.replace("\\", "\\\\").replace('"', '\\"') + '\\n\\t" \\\n')
             f.write('  ""\n')
+        f.write("#define W128_DMA0_ASM \\\n")
+        for line in render(first_tile_dma()):
+            f.write('  "' + line + '\\n\\t" \\\n')
+        f.write('  ""\n')
         # clobber lists
         vs = ", ".join(f'"v{i}"' for i in range(V_CLOBBER[0], V_CLOBBER[1] + 1))
         as_ = ", ".join(f'"a{i}"' for i in range(256))

@@ -21,6 +21,8 @@
 // only the 32 current accumulators and the fold costs nothing per tile.
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "ir_common.h"
 #include "ir_kernels.h"
 
@@ -799,6 +801,17 @@ hipError_t launch(const AttnKParams& p0, hipStream_t s) {
     k = ir_pick_split(rem, slots_x, p.ntiles / 8, (long)(p.ws_bytes / piece_bytes / 8));
   }
   if (k <= 1) { full = p.sk_ix; rem = 0; k = 1; }
+  {
+    // measurement knob (round 6, VERDICT r5 item 5: "the split-K/V form on purpose"): IR_ATTN_FORCE_SPLIT=k cuts EVERY item of the
+    // 32-row kernel's grid into k K/V-range pieces (more resident waves per CU to hide the per-tile latency chain), within the
+    // workspace; read once, off by default.  profiles/r6_small_classes.txt has what it measures.
+    static const int force_k = [] { const char* e = getenv("IR_ATTN_FORCE_SPLIT"); return e != nullptr ? atoi(e) : 0; }();
+    if (force_k > 1 && p.ws != nullptr && p.ntiles >= 2 * force_k) {
+      const size_t piece_bytes = (size_t)QB * (66 + (p.seg_cum != nullptr ? p.nseg_out : 0)) * sizeof(float);
+      const long cap = (long)(p.ws_bytes / piece_bytes / 8);
+      if ((long)p.sk_ix * force_k <= cap) { full = 0; rem = p.sk_ix; k = force_k; }
+    }
+  }
   p.sk_full = full;
   p.sk_k = k;
   p.ws_o = p.ws;

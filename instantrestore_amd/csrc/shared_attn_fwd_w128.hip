@@ -14,7 +14,8 @@
 // Division of labour: the asm statement runs n consecutive tiles of ONE K/V segment (a "run"); everything rare - work decode,
 // segment descriptors, the AdaIN fold at a segment boundary, the epilogue - is C++ around it.  State that outlives a run lives
 // in accumulator registers only (O a[0:127], Q fragments a[128:191], m / l / l_done a[192:203]); the compiler owns v0-v31 and
-// v224-v255 and never touches an AGPR (tools/check_resources.py fails the build on a spill or a compiler v_accvgpr_*).
+// v224-v255 and never touches an AGPR (tools/check_resources.py fails the build on a spill or scratch use of this kernel;
+// tests/test_build_guards.py disassembles it and fails on any compiler-generated v_accvgpr_* / AGPR operand outside the asm blocks).
 #include <type_traits>
 #include <utility>
 

@@ -54,11 +54,14 @@ static __device__ __forceinline__ void static_for(F&& f) {
 }
 
 constexpr int A_O = 0, A_Q = 128, A_M = 192, A_L = 196, A_LD = 200;
+constexpr int FOLD_MAX_SEG = 16;   // segment lists up to 16 entries take their fold coefficients from the LDS table (longer ones: from global memory)
 
 template <typename T, bool FOLD>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) shared_attn_fwd_w128_kernel(const AttnKParams p) {
   using v4 = typename ElemTraits<T>::v4;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];   // K ring of 2, V ring of 2
+  // K ring of 2, V ring of 2 (32 KiB, at LDS offset 0); FOLD: behind it the fold coefficients of every segment boundary
+  // ([segment][another segment follows in this piece][a_cur / a_next | b_cur / a_next][64 channels] fp32, 1 KiB per segment)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES + (FOLD ? FOLD_MAX_SEG * 1024 : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -119,23 +122,37 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1,
       acc_set<A_L + B_>(0.f);
     });
     const bool cur_ref = !(p.include_self && sc == 0);
+    const bool tab = (p.include_self + p.N) <= FOLD_MAX_SEG;
     const int64_t ao_c = ((int64_t)(b * p.N + (cur_ref ? sc - p.include_self : 0)) * p.H + h) * 64 + 4 * hi;
     const int64_t ao_n = ((int64_t)(b * p.N + (has_next ? sc + 1 - p.include_self : 0)) * p.H + h) * 64 + 4 * hi;
+    const float* const trow = (const float*)(smem + 4 * TILE_BYTES) + ((sc * 2 + (has_next ? 1 : 0)) * 2) * 64 + 4 * hi;
     static_for<4>([&](auto g4_) {
       constexpr int g4 = decltype(g4_)::value;
-      f32x4 ac0 = {1.f, 1.f, 1.f, 1.f}, ac1 = ac0, an0 = ac0, an1 = ac0, bc0 = {0.f, 0.f, 0.f, 0.f}, bc1 = bc0;
-      if (cur_ref) {
-        ac0 = *(const f32x4*)(p.aa + ao_c + 8 * g4); ac1 = *(const f32x4*)(p.aa + ao_c + 32 + 8 * g4);
-        bc0 = *(const f32x4*)(p.ab + ao_c + 8 * g4); bc1 = *(const f32x4*)(p.ab + ao_c + 32 + 8 * g4);
-      }
-      if (has_next) {
-        an0 = *(const f32x4*)(p.aa + ao_n + 8 * g4); an1 = *(const f32x4*)(p.aa + ao_n + 32 + 8 * g4);
+      f32x4 s_a0, s_a1, s_b0, s_b1;      // a_cur / a_next and b_cur / a_next of this lane's channels 8 g4 + 4 hi .. + 3 (and + 32)
+      if (tab) {
+        // round 6: computed once per item into LDS by the prologue (same operations, same bits): no loads from global memory,
+        // no divisions and no dependent wait per boundary - the fold was ~5 K cycles per boundary, 2 % of an item at the top layer
+        s_a0 = *(const f32x4*)(trow + 8 * g4); s_a1 = *(const f32x4*)(trow + 32 + 8 * g4);
+        s_b0 = *(const f32x4*)(trow + 64 + 8 * g4); s_b1 = *(const f32x4*)(trow + 96 + 8 * g4);
+      } else {
+        f32x4 ac0 = {1.f, 1.f, 1.f, 1.f}, ac1 = ac0, an0 = ac0, an1 = ac0, bc0 = {0.f, 0.f, 0.f, 0.f}, bc1 = bc0;
+        if (cur_ref) {
+          ac0 = *(const f32x4*)(p.aa + ao_c + 8 * g4); ac1 = *(const f32x4*)(p.aa + ao_c + 32 + 8 * g4);
+          bc0 = *(const f32x4*)(p.ab + ao_c + 8 * g4); bc1 = *(const f32x4*)(p.ab + ao_c + 32 + 8 * g4);
+        }
+        if (has_next) {
+          an0 = *(const f32x4*)(p.aa + ao_n + 8 * g4); an1 = *(const f32x4*)(p.aa + ao_n + 32 + 8 * g4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float i0 = 1.0f / an0[i], i1 = 1.0f / an1[i];
+          s_a0[i] = ac0[i] * i0; s_b0[i] = bc0[i] * i0; s_a1[i] = ac1[i] * i1; s_b1[i] = bc1[i] * i1;
+        }
       }
       static_for<4>([&](auto i_) {
         constexpr int i = decltype(i_)::value;
         constexpr int r = 4 * g4 + i;
-        const float i0 = 1.0f / an0[i], i1 = 1.0f / an1[i];
-        const float sa0 = ac0[i] * i0, sb0 = bc0[i] * i0, sa1 = ac1[i] * i1, sb1 = bc1[i] * i1;
+        const float sa0 = s_a0[i], sb0 = s_b0[i], sa1 = s_a1[i], sb1 = s_b1[i];
         static_for<4>([&](auto blk) {
           constexpr int B_ = decltype(blk)::value;
           acc_set<A_O + 32 * B_ + r>(__builtin_fmaf(acc_get<A_O + 32 * B_ + r>(), sa0, ls[B_] * sb0));
@@ -192,6 +209,25 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(1,
                  : [ko0] "v"(ko0[0]), [ko1] "v"(ko0[1]), [vo0] "v"(vo0[0]), [vo1] "v"(vo0[1]), [kd] "s"(kd0), [vd] "s"(vd0),
                    [ksoff] "s"(ksoff0), [vsoff] "s"(vsoff0), [wb] "s"(wb)
                  : "memory");
+  }
+
+  if (FOLD && (p.include_self + p.N) <= FOLD_MAX_SEG) {
+    // fold coefficients of every segment boundary, both forms (another segment follows in this piece / the piece or the walk ends
+    // here: a_next = 1): one entry per thread and step, coalesced reads of the affine; visible to every wave behind the first
+    // run statement's barrier
+    float* const tabw = (float*)(smem + 4 * TILE_BYTES);
+    const int nseg_all = p.include_self + p.N;
+    for (int e = tid; e < nseg_all * 128; e += NW * 64) {
+      const int sg = e >> 7, var = (e >> 6) & 1, d = e & 63;
+      const bool cref = !(p.include_self && sg == 0);
+      const bool nxt = var == 1 && sg + 1 < nseg_all;
+      const int64_t oc = ((int64_t)(b * p.N + (cref ? sg - p.include_self : 0)) * p.H + h) * 64 + d;
+      const int64_t on = ((int64_t)(b * p.N + (nxt ? sg + 1 - p.include_self : 0)) * p.H + h) * 64 + d;
+      const float ac = cref ? p.aa[oc] : 1.f, bc = cref ? p.ab[oc] : 0.f, an = nxt ? p.aa[on] : 1.f;
+      const float inv = 1.0f / an;
+      tabw[((sg * 2 + var) * 2) * 64 + d] = ac * inv;
+      tabw[((sg * 2 + var) * 2 + 1) * 64 + d] = bc * inv;
+    }
   }
 
   // ---- state: O = 0, m = l = l_done = 0; Q fragments of the four row blocks into a[128:191] ---------------------------------

@@ -49,6 +49,8 @@ CASES = [
     (3, 5, 4096, 4096, 4, 4096, True, True, False),   # 120 items on 256 slots
     (7, 5, 4096, 4096, 2, 4096, False, True, False),  # 280 items: 24 items in the remainder round -> K/V-range pieces + combine
     (1, 5, 4608, 4096, 4, 4096, True, False, False),  # 45 items (nqb = 9)
+    (1, 2, 192, 128, 17, 64, True, True, False),      # 18 segments: more than the LDS fold table holds (coefficients from global memory)
+    (1, 1, 128, 64, 15, 64, True, True, False),       # 16 segments: the table's last slot
 ]
 
 
